@@ -1,0 +1,143 @@
+// Test-only C hooks over the product's header-only field/curve code (host compilation), so that
+// the CPU test-suite can compare it limb-for-limb with the reference oracle (oracle/_ref).
+// Built by __graft_entry__.build() into tests/native/_build/libbz_hooks.so.
+#include <cstring>
+
+#include "blitzar_amd/csrc/curve/ed25519.h"
+#include "blitzar_amd/csrc/curve/weierstrass.h"
+
+using namespace bz;
+
+extern "C" {
+void bz_f51_mul(u64* h, const u64* f, const u64* g) {
+  fe51 a, b;
+  std::memcpy(&a, f, 40);
+  std::memcpy(&b, g, 40);
+  fe51 r = f51::mul(a, b);
+  std::memcpy(h, &r, 40);
+}
+void bz_f51_sq(u64* h, const u64* f) {
+  fe51 a;
+  std::memcpy(&a, f, 40);
+  fe51 r = f51::sq(a);
+  std::memcpy(h, &r, 40);
+}
+void bz_f51_sub(u64* h, const u64* f, const u64* g) {
+  fe51 a, b;
+  std::memcpy(&a, f, 40);
+  std::memcpy(&b, g, 40);
+  fe51 r = f51::sub(a, b);
+  std::memcpy(h, &r, 40);
+}
+void bz_f51_invert(u64* h, const u64* f) {
+  fe51 a;
+  std::memcpy(&a, f, 40);
+  fe51 r = f51::invert(a);
+  std::memcpy(h, &r, 40);
+}
+void bz_ed_base_elements(u64* out, u64 first, u64 n) {
+  for (u64 i = 0; i < n; ++i) {
+    ed_point p = ed::base_element(first + i);
+    std::memcpy(out + 20 * i, &p, 160);
+  }
+}
+void bz_ed_add(u64* out, const u64* a, const u64* b) {
+  ed_point p, q;
+  std::memcpy(&p, a, 160);
+  std::memcpy(&q, b, 160);
+  ed_point r = ed::add(p, q);
+  std::memcpy(out, &r, 160);
+}
+void bz_ed_dbl(u64* out, const u64* a) {
+  ed_point p;
+  std::memcpy(&p, a, 160);
+  ed_point r = ed::dbl(p);
+  std::memcpy(out, &r, 160);
+}
+void bz_ed_dbl_n(u64* out, const u64* a, int k) {
+  ed_point p;
+  std::memcpy(&p, a, 160);
+  ed_point r = ed::dbl_n(p, k);
+  std::memcpy(out, &r, 160);
+}
+void bz_ed_neg(u64* out, const u64* a) {
+  ed_point p;
+  std::memcpy(&p, a, 160);
+  ed_point r = ed::neg(p);
+  std::memcpy(out, &r, 160);
+}
+void bz_ed_sub_cached(u64* out, const u64* a, const u64* b) {
+  ed_point p, q;
+  std::memcpy(&p, a, 160);
+  std::memcpy(&q, b, 160);
+  ed_point r = ed::to_point(ed::sub_cached(p, ed::to_cached(q)));
+  std::memcpy(out, &r, 160);
+}
+void bz_ristretto_encode(u8* out, const u64* a) {
+  ed_point p;
+  std::memcpy(&p, a, 160);
+  ristretto::encode(out, p);
+}
+int bz_ristretto_decode(u64* out, const u8* s) {
+  ed_point p;
+  bool ok = ristretto::decode(p, s);
+  std::memcpy(out, &p, 160);
+  return ok ? 0 : -1;
+}
+
+#define BZ_SW_HOOKS(PFX, G)                                                                        \
+  void bz_##PFX##_field_mul(u64* h, const u64* f, const u64* g) {                                  \
+    G::fe a, b;                                                                                    \
+    std::memcpy(&a, f, sizeof(a));                                                                 \
+    std::memcpy(&b, g, sizeof(b));                                                                 \
+    G::fe r = G::F::mul(a, b);                                                                     \
+    std::memcpy(h, &r, sizeof(r));                                                                 \
+  }                                                                                                \
+  void bz_##PFX##_field_addsub(u64* s, u64* d, const u64* f, const u64* g) {                       \
+    G::fe a, b;                                                                                    \
+    std::memcpy(&a, f, sizeof(a));                                                                 \
+    std::memcpy(&b, g, sizeof(b));                                                                 \
+    G::fe r = G::F::add(a, b);                                                                     \
+    std::memcpy(s, &r, sizeof(r));                                                                 \
+    r = G::F::sub(a, b);                                                                           \
+    std::memcpy(d, &r, sizeof(r));                                                                 \
+  }                                                                                                \
+  void bz_##PFX##_add(u64* out, const u64* a, const u64* b) {                                      \
+    G::point p, q;                                                                                 \
+    std::memcpy(&p, a, sizeof(p));                                                                 \
+    std::memcpy(&q, b, sizeof(q));                                                                 \
+    G::point r = G::add(p, q);                                                                     \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }                                                                                                \
+  void bz_##PFX##_add_mixed(u64* out, const u64* a, const u64* b_affine) {                         \
+    G::point p;                                                                                    \
+    G::affine q;                                                                                   \
+    std::memcpy(&p, a, sizeof(p));                                                                 \
+    std::memcpy(&q, b_affine, sizeof(q));                                                          \
+    G::point r = G::add_mixed(p, q);                                                               \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }                                                                                                \
+  void bz_##PFX##_dbl(u64* out, const u64* a) {                                                    \
+    G::point p;                                                                                    \
+    std::memcpy(&p, a, sizeof(p));                                                                 \
+    G::point r = G::dbl(p);                                                                        \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }                                                                                                \
+  int bz_##PFX##_to_affine(u64* out_xy, const u64* a) {                                            \
+    G::point p;                                                                                    \
+    std::memcpy(&p, a, sizeof(p));                                                                 \
+    G::affine r;                                                                                   \
+    bool inf = G::to_affine(r, p);                                                                 \
+    std::memcpy(out_xy, &r, sizeof(r));                                                            \
+    return inf ? 1 : 0;                                                                            \
+  }
+BZ_SW_HOOKS(bn254, bn254_g1)
+BZ_SW_HOOKS(grumpkin, grumpkin_g)
+BZ_SW_HOOKS(bls12_381, bls12_381_g1)
+
+void bz_bls12_381_compress(u8* out48, const u64* a) {
+  bls12_381_g1::point p;
+  std::memcpy(&p, a, sizeof(p));
+  bls12_381_g1_compress(out48, p);
+}
+}
