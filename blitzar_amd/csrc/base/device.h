@@ -1,0 +1,91 @@
+// Minimal HIP runtime plumbing for the engine: loud error checks (the C ABI of the reference has
+// no error channel -- sxt/base/error/panic.h:68-79 aborts on every CUDA error, and so do we),
+// a grow-only device arena, and device discovery.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+
+#include "blitzar_amd/csrc/base/macros.h"
+
+#define BZ_HIP_CHECK(expr)                                                                         \
+  do {                                                                                             \
+    hipError_t bz_err__ = (expr);                                                                  \
+    if (bz_err__ != hipSuccess) {                                                                  \
+      std::fprintf(stderr, "blitzar_amd: %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__,    \
+                   hipGetErrorString(bz_err__));                                                   \
+      std::abort();                                                                                \
+    }                                                                                              \
+  } while (0)
+
+#define BZ_RELEASE_ASSERT(cond, msg)                                                               \
+  do {                                                                                             \
+    if (!(cond)) {                                                                                 \
+      std::fprintf(stderr, "blitzar_amd: %s:%d failed assert: [%s]. %s\n", __FILE__, __LINE__,    \
+                   #cond, msg);                                                                    \
+      std::abort();                                                                                \
+    }                                                                                              \
+  } while (0)
+
+namespace bz {
+
+// gfx950 kernel launches issued so far (exported as bzamd_kernel_launch_count; the GPU tests use it
+// to prove the HIP path produced a result)
+extern std::atomic<u64> g_kernel_launches;
+
+inline int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// Grow-only bump arena: one hipMalloc that is reused across calls and re-allocated (after a
+// stream sync) only when a call needs more.  288 GB of HBM makes "keep the high-water mark"
+// the right policy for a commitment service.
+class device_arena {
+public:
+  device_arena() = default;
+  device_arena(const device_arena&) = delete;
+  device_arena& operator=(const device_arena&) = delete;
+  ~device_arena() {
+    if (base_ != nullptr) (void)hipFree(base_);
+  }
+
+  // start a new call needing `bytes` in total
+  void reset(size_t bytes, hipStream_t stream) {
+    if (bytes > capacity_) {
+      if (base_ != nullptr) {
+        BZ_HIP_CHECK(hipStreamSynchronize(stream));
+        BZ_HIP_CHECK(hipFree(base_));
+        base_ = nullptr;
+      }
+      size_t cap = bytes + bytes / 8;
+      BZ_HIP_CHECK(hipMalloc(&base_, cap));
+      capacity_ = cap;
+    }
+    used_ = 0;
+  }
+
+  template <class T> T* take(size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) & ~size_t{255};
+    BZ_RELEASE_ASSERT(used_ + bytes <= capacity_, "device arena overflow");
+    T* p = reinterpret_cast<T*>(static_cast<char*>(base_) + used_);
+    used_ += bytes;
+    return p;
+  }
+
+  static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t{255}; }
+  size_t capacity() const { return capacity_; }
+
+private:
+  void* base_ = nullptr;
+  size_t capacity_ = 0;
+  size_t used_ = 0;
+};
+} // namespace bz

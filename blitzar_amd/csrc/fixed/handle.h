@@ -1,0 +1,22 @@
+// `sxt_multiexp_handle`: generators fixed at creation, reused by many multiexponentiations
+// (reference: cbnb::multiexp_handle {curve_id, partition_table_accessor},
+// sxt/cbindings/base/multiexp_handle.h:28-31).  The native handle keeps one resident addend per
+// generator in HBM instead of the reference's 2^w-entry partition tables (64 GiB for 2^18 Grumpkin
+// generators at w = 16); the table format only appears at the file boundary
+// (fixed/partition_table.h).
+#pragma once
+
+#include <vector>
+
+#include "blitzar_amd/csrc/msm/dispatch.h"
+
+namespace bz {
+struct multiexp_handle {
+  const curve_vtable* vt = nullptr;
+  u64 n = 0;                 // generators (file-loaded handles include the identity padding)
+  unsigned window_width = 16; // only used when the handle is written to a file
+  std::vector<u8> host_projective; // n projective elements (host copy)
+  void* d_addends = nullptr;       // GPU backend: resident addends
+  int device = 0;
+};
+} // namespace bz

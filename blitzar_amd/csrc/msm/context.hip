@@ -1,0 +1,23 @@
+// msm_context lifetime + curve id dispatch.
+#include "blitzar_amd/csrc/msm/dispatch.h"
+#include "blitzar_amd/csrc/msm/engine.h"
+
+namespace bz {
+const curve_vtable* curve_vtable_for(unsigned curve_id) {
+  switch (curve_id) {
+  case 0:
+    return &curve25519_vtable();
+  case 1:
+    return &bls12_381_vtable();
+  case 2:
+    return &bn254_vtable();
+  case 3:
+    return &grumpkin_vtable();
+  default:
+    return nullptr;
+  }
+}
+
+msm_context* msm_context_new() { return new msm_context(); }
+void msm_context_free(msm_context* ctx) { delete ctx; }
+} // namespace bz

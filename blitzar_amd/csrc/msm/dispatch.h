@@ -1,0 +1,52 @@
+// Type-erased entry points of the per-curve MSM translation units (msm_<curve>.hip).  Each curve
+// is compiled in its own TU so the four gfx950 code objects build in parallel.
+#pragma once
+
+#include <cstdio>
+#include <vector>
+
+#include "blitzar_amd/csrc/base/device.h"
+#include "blitzar_amd/csrc/msm/plan.h"
+
+namespace bz {
+
+struct msm_context;
+
+struct curve_vtable {
+  unsigned curve_id;
+  size_t api_generator_size; // stride of caller generators in the C ABI
+  size_t addend_size;        // resident addend
+  size_t output_size;        // canonical commitment encoding
+  size_t projective_size;    // raw projective element (fixed-base results, handle generators)
+  // enqueue a variable-base MSM; exactly one of d_addends / d_api_generators is used
+  void (*msm)(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+              const std::vector<host_column>& cols, const void* d_addends,
+              const void* d_api_generators, hipStream_t stream);
+  // C-ABI generators -> resident addends
+  void (*prepare_addends)(void* d_addends, const void* d_api_generators, u64 n, hipStream_t stream);
+  // projective elements (handle generators) -> resident addends (batch normalisation on device)
+  void (*prepare_addends_projective)(void* d_addends, const void* d_projective, u64 n,
+                                     hipStream_t stream);
+  // SXT_CPU_BACKEND: all pointers are host pointers; generators in C-ABI layout, or in
+  // projective layout when `generators_projective`
+  void (*msm_host)(u8* out, u32 out_stride, bool projective_out,
+                   const std::vector<host_column>& cols, const void* generators,
+                   bool generators_projective, u64 num_generators);
+  // partition-table file interop of fixed-base handles (fixed/partition_table.h)
+  size_t compact_size;
+  void (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);
+  bool (*read_partition_generators)(std::FILE* f, unsigned& window_width,
+                                    std::vector<u8>& projective_out, u64& n);
+};
+
+const curve_vtable& curve25519_vtable();
+const curve_vtable& bls12_381_vtable();
+const curve_vtable& bn254_vtable();
+const curve_vtable& grumpkin_vtable();
+
+// nullptr for an unknown id
+const curve_vtable* curve_vtable_for(unsigned curve_id);
+
+msm_context* msm_context_new();
+void msm_context_free(msm_context* ctx);
+} // namespace bz

@@ -1,0 +1,118 @@
+// Host orchestration of one variable-base MSM call on one device: plan -> arena carve-up ->
+// kernel sequence on a single HIP stream.  Everything is asynchronous with respect to the host;
+// callers synchronise the stream (the C ABI entry points do, they are blocking like the
+// reference's).
+#pragma once
+
+#include <vector>
+
+#include "blitzar_amd/csrc/base/device.h"
+#include "blitzar_amd/csrc/msm/kernels.h"
+
+namespace bz {
+
+struct msm_context {
+  device_arena arena;
+  msm_tuning tuning;
+};
+
+template <class C> struct msm_workspace_sizes {
+  size_t total = 0;
+};
+
+// Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.
+inline msm_plan plan_for_columns(const std::vector<host_column>& cols, const msm_tuning& tune) {
+  bool any_signed = false;
+  for (const auto& c : cols) any_signed = any_signed || c.is_signed;
+  msm_tuning t = tune;
+  if (any_signed && t.max_window_bits > 15) t.max_window_bits = 15;
+  return make_msm_plan(cols, t);
+}
+
+// one-time k_bucket_sort attribute: it needs up to 128 KiB + of dynamic LDS
+static void configure_sort_kernel() {
+  static bool done = false;
+  if (done) return;
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  done = true;
+}
+
+// Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
+// (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
+template <class C>
+void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                 const std::vector<host_column>& cols, const typename C::addend* d_addends,
+                 const void* d_api_generators, hipStream_t stream) {
+  using point = typename C::point;
+  using addend = typename C::addend;
+  if (cols.empty()) return;
+  configure_sort_kernel();
+  const msm_plan plan = plan_for_columns(cols, ctx.tuning);
+  const u32 num_tasks = static_cast<u32>(plan.tasks.size());
+  const u32 num_cols = static_cast<u32>(plan.columns.size());
+  const u32 partial_stride =
+      plan.max_task_buckets == 0 ? 1 : ceil_div_u32(plan.max_task_buckets, kReduceBlockBuckets);
+
+  size_t need = 0;
+  need += device_arena::padded(sizeof(column_desc) * num_cols);
+  need += device_arena::padded(sizeof(task_desc) * (num_tasks + 1));
+  if (d_addends == nullptr) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
+  need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
+  need += device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
+  need += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
+  need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
+  need += device_arena::padded(sizeof(point) * (static_cast<size_t>(num_tasks) * partial_stride + 1));
+  ctx.arena.reset(need, stream);
+
+  column_desc* d_cols = ctx.arena.take<column_desc>(num_cols);
+  task_desc* d_tasks = ctx.arena.take<task_desc>(num_tasks + 1);
+  BZ_HIP_CHECK(hipMemcpyAsync(d_cols, plan.columns.data(), sizeof(column_desc) * num_cols,
+                              hipMemcpyHostToDevice, stream));
+  if (num_tasks > 0) {
+    BZ_HIP_CHECK(hipMemcpyAsync(d_tasks, plan.tasks.data(), sizeof(task_desc) * num_tasks,
+                                hipMemcpyHostToDevice, stream));
+  }
+
+  if (num_tasks > 0) {
+    if (d_addends == nullptr) {
+      addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
+      const u32 blocks = ceil_div_u32(plan.max_rows, 256);
+      hipLaunchKernelGGL((k_prepare_addends<C>), dim3(blocks), dim3(256), 0, stream, prepared,
+                         d_api_generators, plan.max_rows);
+      d_addends = prepared;
+    }
+    i16* d_digits = ctx.arena.take<i16>(plan.total_entries + 8);
+    u32* d_sorted = ctx.arena.take<u32>(plan.total_entries + 8);
+    u32* d_bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
+    point* d_bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
+    point* d_partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * partial_stride + 1);
+
+    hipLaunchKernelGGL(k_recode, dim3(ceil_div_u32(plan.max_rows, 256), num_cols), dim3(256), 0,
+                       stream, d_digits, d_cols, d_tasks);
+
+    const size_t sort_lds = sizeof(u32) * plan.max_task_buckets;
+    hipLaunchKernelGGL(k_bucket_sort, dim3(num_tasks), dim3(kSortThreads), sort_lds, stream,
+                       d_sorted, d_bucket_end, d_digits, d_tasks);
+
+    hipLaunchKernelGGL((k_accumulate<C>),
+                       dim3(ceil_div_u32(plan.max_task_buckets, kAccumulateThreads), num_tasks),
+                       dim3(kAccumulateThreads), 0, stream, d_bucket_sums, d_bucket_end, d_sorted,
+                       d_addends, d_tasks);
+
+    hipLaunchKernelGGL((k_reduce<C>), dim3(partial_stride, num_tasks), dim3(kReduceThreads), 0,
+                       stream, d_partials, partial_stride, d_bucket_sums, d_bucket_end, d_tasks);
+
+    hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
+                       out_stride, projective_out ? 1 : 0, d_partials, partial_stride, d_cols,
+                       d_tasks);
+  } else {
+    // every column is empty: identities only
+    hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
+                       out_stride, projective_out ? 1 : 0, nullptr, partial_stride, d_cols, d_tasks);
+  }
+  g_kernel_launches += num_tasks > 0 ? 5 : 1;
+  BZ_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace bz

@@ -1,0 +1,6 @@
+// gfx950 code object for the grumpkin MSM kernels (see curve_tu.h / kernels.h).
+#include "blitzar_amd/csrc/msm/curve_tu.h"
+
+namespace bz {
+const curve_vtable& grumpkin_vtable() { return curve_tu<grumpkin_msm>::vtable(); }
+} // namespace bz

@@ -1,0 +1,108 @@
+// Signed radix-2^c recoding of one scalar, shared by the device kernel (k_recode) and the host
+// backend.  A scalar is a little-endian bit field of 1..256 bits inside its row (byte-aligned
+// `nbytes`-wide for the Pedersen API, arbitrary offsets for the packed fixed-base API,
+// cbindings/blitzar_api.h:688-712), two's complement when the column is signed (reference semantics: sxt/multiexp/base/exponent_sequence.h:25-42, abs handling
+// sxt/base/num/abs.h:43-53).  Digits D_w satisfy  x = sum_w D_w 2^(c w),  |D_w| <= 2^(c-1),
+// and the top digit never carries as long as W * c >= bit_width + 1.
+#pragma once
+
+#include "blitzar_amd/csrc/base/macros.h"
+
+namespace bz {
+
+struct digit_recoder {
+  u64 w[4];
+  u32 c;
+  u32 half;
+  u32 carry;
+  u32 bit;
+  bool negative;
+
+  // little-endian bit field [bit_offset, bit_offset + bit_width) of the row at `p`
+  BZ_HD void load(const u8* __restrict__ p, u32 bit_offset, u32 bit_width) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    p += bit_offset >> 3;
+    const u32 sh = bit_offset & 7;
+    if (sh == 0 && bit_width == 256 && (reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+      const u64* q = reinterpret_cast<const u64*>(p);
+      w[0] = q[0];
+      w[1] = q[1];
+      w[2] = q[2];
+      w[3] = q[3];
+      return;
+    }
+    const u32 nbytes = (sh + bit_width + 7) >> 3; // <= 33
+    u64 t[5] = {0, 0, 0, 0, 0};
+    for (u32 i = 0; i < nbytes; ++i) {
+      t[i >> 3] |= static_cast<u64>(p[i]) << (8 * (i & 7));
+    }
+    if (sh != 0) {
+      for (int i = 0; i < 4; ++i) t[i] = (t[i] >> sh) | (t[i + 1] << (64 - sh));
+    }
+    for (int i = 0; i < 4; ++i) {
+      const u32 lo = 64 * i;
+      if (bit_width <= lo) {
+        w[i] = 0;
+      } else if (bit_width < lo + 64) {
+        w[i] = t[i] & ((u64{1} << (bit_width - lo)) - 1);
+      } else {
+        w[i] = t[i];
+      }
+    }
+  }
+
+  BZ_HD void init(const u8* __restrict__ p, u32 bit_offset, u32 bit_width, bool is_signed,
+                  u32 window_bits) {
+    load(p, bit_offset, bit_width);
+    c = window_bits;
+    half = 1u << (c - 1);
+    carry = 0;
+    bit = 0;
+    negative = false;
+    if (is_signed) {
+      const u32 nbits = bit_width;
+      const u32 top = nbits - 1;
+      negative = ((w[top >> 6] >> (top & 63)) & 1) != 0;
+      if (negative) {
+        // |x| = 2^nbits - x, computed over the nbits-wide field
+        u64 cin = 1;
+        for (int i = 0; i < 4; ++i) {
+          const u64 v = ~w[i] + cin;
+          cin = (cin != 0 && v == 0) ? 1 : 0;
+          w[i] = v;
+        }
+        for (int i = 0; i < 4; ++i) {
+          const u32 lo = 64 * i;
+          if (nbits <= lo) {
+            w[i] = 0;
+          } else if (nbits < lo + 64) {
+            w[i] &= (u64{1} << (nbits - lo)) - 1;
+          }
+        }
+      }
+    }
+  }
+
+  // next signed digit, least-significant window first, column sign already applied
+  BZ_HD int next() {
+    u32 u = 0;
+    if (bit < 256) {
+      const u32 word = bit >> 6, sh = bit & 63;
+      u64 v = w[word] >> sh;
+      if (sh + c > 64 && word + 1 < 4) v |= w[word + 1] << (64 - sh);
+      u = static_cast<u32>(v) & ((1u << c) - 1);
+    }
+    bit += c;
+    const u32 t = u + carry;
+    int d;
+    if (t > half) {
+      d = static_cast<int>(t) - static_cast<int>(1u << c);
+      carry = 1;
+    } else {
+      d = static_cast<int>(t);
+      carry = 0;
+    }
+    return negative ? -d : d;
+  }
+};
+} // namespace bz

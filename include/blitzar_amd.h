@@ -1,0 +1,76 @@
+/* MI355X-native extensions next to the drop-in Blitzar ABI (include/blitzar_api.h).
+ *
+ * The reference API only accepts host buffers and re-uploads scalars and generators on every
+ * call (sxt/multiexp/bucket_method/accumulation.h:68-71, bucket_method2/sum.h:103-107).  These
+ * entry points are what SURVEY.md section 8(f) row 1 asks for: the same computation on operands that are
+ * already resident in HBM, enqueued on a caller stream.  They are also what `bench.py` times
+ * ("inputs already resident in HBM when the timed region starts").
+ *
+ * All pointers marked DEVICE must be valid on the current HIP device.  `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  Calls are asynchronous unless stated otherwise.
+ */
+#ifndef BLITZAR_AMD_BLITZAR_AMD_H
+#define BLITZAR_AMD_BLITZAR_AMD_H
+
+#include <stdint.h>
+
+#include "blitzar_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library / device introspection */
+const char* bzamd_version(void);
+int bzamd_device_count(void);
+/* 0 = not initialised, SXT_CPU_BACKEND, SXT_GPU_BACKEND */
+int bzamd_active_backend(void);
+/* number of gfx950 kernel launches issued by this process so far (tests use it to prove that the
+ * HIP path, not a host path, produced a result) */
+uint64_t bzamd_kernel_launch_count(void);
+/* drop the backend singleton so that sxt_init may be called again (reference:
+ * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
+void bzamd_reset_for_testing(void);
+
+/* Variable-base MSM on device-resident operands.
+ *   commitments  DEVICE  num_sequences canonical encodings (32 / 48 / 72 / 72 bytes each)
+ *   descriptors  HOST    array whose `data` members are DEVICE pointers
+ *   generators   DEVICE  C-ABI layout of the curve (sxt_ristretto255[160] / bls 104-byte stride /
+ *                        sxt_bn254_g1[72] / sxt_grumpkin[72]), max_i n_i entries
+ * Same validation/abort behaviour as the sxt_*_compute_pedersen_commitments_with_generators calls. */
+void bzamd_msm_device(unsigned curve_id, void* commitments, uint32_t num_sequences,
+                      const struct sxt_sequence_descriptor* descriptors, const void* generators,
+                      void* stream);
+
+/* Resident generator set: generators converted once into the engine's addend layout and kept in
+ * HBM across calls. */
+struct bzamd_generators;
+/* from DEVICE generators in C-ABI layout (blocking) */
+struct bzamd_generators* bzamd_generators_new_device(unsigned curve_id, const void* generators,
+                                                     uint64_t n, void* stream);
+/* from HOST generators in C-ABI layout (blocking) */
+struct bzamd_generators* bzamd_generators_new_host(unsigned curve_id, const void* generators,
+                                                   uint64_t n);
+void bzamd_generators_free(struct bzamd_generators* gens);
+void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
+                               const struct sxt_sequence_descriptor* descriptors,
+                               const struct bzamd_generators* gens, void* stream);
+
+/* DEVICE built-in ristretto generators g_first .. g_first+n-1 as sxt_ristretto255 (async) */
+void bzamd_ristretto255_generators_device(struct sxt_ristretto255* generators, uint64_t first,
+                                          uint64_t n, void* stream);
+
+/* Fixed-base (handle) MSM with DEVICE scalars and DEVICE results; same packing rules as
+ * sxt_fixed_packed_multiexponentiation / sxt_fixed_vlen_multiexponentiation
+ * (output_lengths may be NULL = all rows). */
+void bzamd_fixed_packed_multiexponentiation_device(void* res, const struct sxt_multiexp_handle* handle,
+                                                   const unsigned* output_bit_table,
+                                                   const unsigned* output_lengths,
+                                                   unsigned num_outputs, unsigned n,
+                                                   const uint8_t* scalars, void* stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* BLITZAR_AMD_BLITZAR_AMD_H */
