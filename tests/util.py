@@ -1,0 +1,67 @@
+"""Shared builders for parity tests (inputs only; expected values always come from the oracle)."""
+import numpy as np
+
+from oracle import ref_oracle
+
+
+def mt_bytes(seed, n):
+    """byte stream of std::mt19937{seed} through uniform_int_distribution<uint8_t> is not
+    reproducible from numpy; tests only need *seeded* bytes, bench.py documents its own stream."""
+    return np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)
+
+
+def weierstrass_generators(curve_id, n, distinct_seeds=64):
+    """n affine generators in C-ABI layout: the first `distinct_seeds` come from the reference's
+    generate_random_element(rng{i+1, i+2}); the rest continue g_i = g_{i-1} + g_0 (the recipe of
+    SURVEY 8(d) for big generator sets).  Index 5 (if present) is the identity."""
+    _, nl, stride, _ = ref_oracle.CURVES[curve_id]
+    out = np.zeros((n, stride), dtype=np.uint8)
+    k = min(n, distinct_seeds)
+    for i in range(k):
+        out[i] = ref_oracle.random_affine(curve_id, i + 1, i + 2)
+    if n > k:
+        one = ref_oracle.identity_affine(curve_id)[8 * nl:16 * nl].view(np.uint64)
+
+        def p2(a):
+            return np.concatenate([a[:16 * nl].view(np.uint64), one])
+        g0 = p2(out[0])
+        acc = p2(out[k - 1])
+        for i in range(k, n):
+            acc = ref_oracle.add_projective(curve_id, acc, g0)
+            out[i] = ref_oracle.to_affine(curve_id, acc)
+            acc = p2(out[i])
+    if n > 5:
+        out[5] = ref_oracle.identity_affine(curve_id)
+    return out
+
+
+def generators_for(curve_id, n):
+    if curve_id == 0:
+        return ref_oracle.ristretto_generators(n)
+    return weierstrass_generators(curve_id, n)
+
+
+def api_generators(curve_id, gens):
+    """oracle-side generator array -> uint8 C-ABI view for blitzar_amd.api"""
+    return np.ascontiguousarray(gens).view(np.uint8).reshape(gens.shape[0], -1)
+
+
+def mixed_columns(rng, n, include_signed=True):
+    """columns covering the reference exerciser's cases (sxt/multiexp/test/multiexponentiation.cc:
+    42-451): every width 1..32, unequal lengths, empty, zeros, all-ones, signed extremes."""
+    cols = []
+    for nb in (1, 2, 3, 4, 5, 8, 13, 16, 24, 31, 32):
+        m = int(rng.integers(0, n + 1))
+        cols.append((rng.integers(0, 256, (m, nb), dtype=np.uint8), False))
+    if include_signed:
+        for nb in (1, 2, 4, 8, 16):
+            m = int(rng.integers(1, n + 1))
+            cols.append((rng.integers(0, 256, (m, nb), dtype=np.uint8), True))
+        cols.append((np.array([-128, 127, -1, 0, 1][:n], dtype=np.int8), True))
+        cols.append((np.array([-2**63, 2**63 - 1, -1][:n], dtype=np.int64), True))
+    cols.append((np.full((n, 32), 0xff, dtype=np.uint8), False))      # 2^256 - 1 everywhere
+    cols.append((np.zeros((n, 8), dtype=np.uint8), False))            # all-zero sequence
+    cols.append((np.zeros((0, 4), dtype=np.uint8), False))            # empty sequence
+    cols.append((np.array([0, 1, 2, 3][:n], dtype=np.uint64), False))
+    cols.append((np.array([2**64 - 1] * min(n, 3), dtype=np.uint64), False))
+    return cols
