@@ -89,6 +89,10 @@ def load():
     lib.bzamd_active_backend.restype = ctypes.c_int
     lib.bzamd_kernel_launch_count.restype = ctypes.c_uint64
     lib.bzamd_reset_for_testing.restype = None
+    lib.bzamd_stage_timing_begin.argtypes = [u64]
+    lib.bzamd_stage_timing_begin.restype = None
+    lib.bzamd_stage_timing_collect.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.bzamd_stage_timing_collect.restype = ctypes.c_uint64
     lib.bzamd_msm_device.argtypes = [cu, vp, u32, ctypes.POINTER(sxt_sequence_descriptor), vp, vp]
     lib.bzamd_msm_device.restype = None
     lib.bzamd_generators_new_device.argtypes = [cu, vp, u64, vp]

@@ -533,6 +533,18 @@ int bzamd_active_backend(void) { return g_state == nullptr ? 0 : g_state->backen
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
 
+void bzamd_stage_timing_begin(uint64_t max_calls) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "stage timing needs the GPU backend");
+  msm_context_timing_begin(st.context_for_current_device(), max_calls);
+}
+
+uint64_t bzamd_stage_timing_collect(double* out_ms) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "stage timing needs the GPU backend");
+  return msm_context_timing_collect(st.context_for_current_device(), out_ms);
+}
+
 void bzamd_reset_for_testing(void) {
   if (g_state == nullptr) return;
   delete g_state;

@@ -20,4 +20,8 @@ const curve_vtable* curve_vtable_for(unsigned curve_id) {
 
 msm_context* msm_context_new() { return new msm_context(); }
 void msm_context_free(msm_context* ctx) { delete ctx; }
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls) { ctx->timer.begin(max_calls); }
+size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]) {
+  return ctx->timer.collect(out_ms);
+}
 } // namespace bz

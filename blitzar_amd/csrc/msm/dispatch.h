@@ -49,4 +49,8 @@ const curve_vtable* curve_vtable_for(unsigned curve_id);
 
 msm_context* msm_context_new();
 void msm_context_free(msm_context* ctx);
+// per-stage HIP-event timing of the next `max_calls` MSM calls on this context
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls);
+// accumulated ms per stage {prepare, recode, sort, accumulate, reduce, combine}; returns #calls
+size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]);
 } // namespace bz

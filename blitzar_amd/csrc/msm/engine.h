@@ -11,9 +11,55 @@
 
 namespace bz {
 
+// Optional per-stage device timing (HIP events on the launch stream), used by bench.py to report
+// the dominant kernel's measured duration next to its algorithmic bytes.
+constexpr int kNumStages = 6; // prepare, recode, sort, accumulate, reduce, combine
+struct stage_timer {
+  bool enabled = false;
+  std::vector<hipEvent_t> events; // (kNumStages + 1) per recorded call
+  size_t calls = 0;
+  size_t capacity_calls = 0;
+
+  void begin(size_t max_calls) {
+    release();
+    events.resize(max_calls * (kNumStages + 1));
+    for (auto& e : events) BZ_HIP_CHECK(hipEventCreate(&e));
+    capacity_calls = max_calls;
+    calls = 0;
+    enabled = true;
+  }
+  hipEvent_t event(int stage) { return events[calls * (kNumStages + 1) + stage]; }
+  bool recording() const { return enabled && calls < capacity_calls; }
+  // accumulated milliseconds per stage over the recorded calls (blocks until they finished)
+  size_t collect(double out_ms[kNumStages]) {
+    for (int s = 0; s < kNumStages; ++s) out_ms[s] = 0;
+    for (size_t c = 0; c < calls; ++c) {
+      hipEvent_t* ev = &events[c * (kNumStages + 1)];
+      BZ_HIP_CHECK(hipEventSynchronize(ev[kNumStages]));
+      for (int s = 0; s < kNumStages; ++s) {
+        float ms = 0;
+        BZ_HIP_CHECK(hipEventElapsedTime(&ms, ev[s], ev[s + 1]));
+        out_ms[s] += ms;
+      }
+    }
+    const size_t n = calls;
+    release();
+    return n;
+  }
+  void release() {
+    for (auto& e : events) (void)hipEventDestroy(e);
+    events.clear();
+    enabled = false;
+    calls = 0;
+    capacity_calls = 0;
+  }
+  ~stage_timer() { release(); }
+};
+
 struct msm_context {
   device_arena arena;
   msm_tuning tuning;
+  stage_timer timer;
 };
 
 template <class C> struct msm_workspace_sizes {
@@ -74,7 +120,12 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
                                 hipMemcpyHostToDevice, stream));
   }
 
+  const bool timing = ctx.timer.recording() && num_tasks > 0;
+  auto mark = [&](int stage) {
+    if (timing) BZ_HIP_CHECK(hipEventRecord(ctx.timer.event(stage), stream));
+  };
   if (num_tasks > 0) {
+    mark(0);
     if (d_addends == nullptr) {
       addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
       const u32 blocks = ceil_div_u32(plan.max_rows, 256);
@@ -88,24 +139,31 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     point* d_bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
     point* d_partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * partial_stride + 1);
 
+    mark(1);
     hipLaunchKernelGGL(k_recode, dim3(ceil_div_u32(plan.max_rows, 256), num_cols), dim3(256), 0,
                        stream, d_digits, d_cols, d_tasks);
+    mark(2);
 
     const size_t sort_lds = sizeof(u32) * plan.max_task_buckets;
     hipLaunchKernelGGL(k_bucket_sort, dim3(num_tasks), dim3(kSortThreads), sort_lds, stream,
                        d_sorted, d_bucket_end, d_digits, d_tasks);
+    mark(3);
 
     hipLaunchKernelGGL((k_accumulate<C>),
                        dim3(ceil_div_u32(plan.max_task_buckets, kAccumulateThreads), num_tasks),
                        dim3(kAccumulateThreads), 0, stream, d_bucket_sums, d_bucket_end, d_sorted,
                        d_addends, d_tasks);
+    mark(4);
 
     hipLaunchKernelGGL((k_reduce<C>), dim3(partial_stride, num_tasks), dim3(kReduceThreads), 0,
                        stream, d_partials, partial_stride, d_bucket_sums, d_bucket_end, d_tasks);
+    mark(5);
 
     hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
                        out_stride, projective_out ? 1 : 0, d_partials, partial_stride, d_cols,
                        d_tasks);
+    mark(6);
+    if (timing) ctx.timer.calls += 1;
   } else {
     // every column is empty: identities only
     hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,

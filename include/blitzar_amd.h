@@ -32,6 +32,14 @@ uint64_t bzamd_kernel_launch_count(void);
  * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
 void bzamd_reset_for_testing(void);
 
+/* Per-stage device timing of the next `max_calls` MSM calls issued on the current device, measured
+ * with HIP events on the launch stream.  `bzamd_stage_timing_collect` blocks until those calls
+ * finished, writes the accumulated milliseconds of the six stages
+ * {prepare_addends, recode, bucket_sort, accumulate, reduce, combine} to out_ms[6] and returns the
+ * number of calls recorded. */
+void bzamd_stage_timing_begin(uint64_t max_calls);
+uint64_t bzamd_stage_timing_collect(double* out_ms);
+
 /* Variable-base MSM on device-resident operands.
  *   commitments  DEVICE  num_sequences canonical encodings (32 / 48 / 72 / 72 bytes each)
  *   descriptors  HOST    array whose `data` members are DEVICE pointers
