@@ -95,6 +95,15 @@ def load():
     lib.bzamd_stage_timing_collect.restype = ctypes.c_uint64
     lib.bzamd_msm_device.argtypes = [cu, vp, u32, ctypes.POINTER(sxt_sequence_descriptor), vp, vp]
     lib.bzamd_msm_device.restype = None
+    lib.bzamd_msm_device_projective.argtypes = [cu, vp, u32,
+                                                ctypes.POINTER(sxt_sequence_descriptor), vp, vp]
+    lib.bzamd_msm_device_projective.restype = None
+    lib.bzamd_msm_projective.argtypes = [cu, vp, u32, ctypes.POINTER(sxt_sequence_descriptor), vp]
+    lib.bzamd_msm_projective.restype = None
+    lib.bzamd_fold_encode.argtypes = [cu, vp, vp, u32, u32]
+    lib.bzamd_fold_encode.restype = None
+    lib.bzamd_fold_encode_device.argtypes = [cu, vp, vp, u32, u32, vp]
+    lib.bzamd_fold_encode_device.restype = None
     lib.bzamd_generators_new_device.argtypes = [cu, vp, u64, vp]
     lib.bzamd_generators_new_device.restype = vp
     lib.bzamd_generators_new_host.argtypes = [cu, vp, u64]
@@ -166,6 +175,25 @@ def compute_pedersen_commitments(curve_id, columns, generators=None, offset_gene
     }[curve_id]
     gens = np.ascontiguousarray(generators)
     fn(_ptr(out), num, descs, _ptr(gens))
+    return out
+
+
+def msm_projective(curve_id, columns, generators):
+    """raw projective MSM results (host operands), one element per column"""
+    lib = load()
+    descs, keep = make_descriptors(columns)
+    out = np.zeros((len(keep), CURVE_LAYOUT[curve_id][2]), dtype=np.uint8)
+    gens = np.ascontiguousarray(generators)
+    lib.bzamd_msm_projective(curve_id, _ptr(out), len(keep), descs, _ptr(gens))
+    return out
+
+
+def fold_encode(curve_id, partials):
+    """partials: uint8 [num_partials, num_outputs, projective bytes] -> canonical [num_outputs, .]"""
+    p = np.ascontiguousarray(partials, dtype=np.uint8)
+    num_partials, num_outputs = p.shape[0], p.shape[1]
+    out = np.zeros((num_outputs, CURVE_LAYOUT[curve_id][1]), dtype=np.uint8)
+    load().bzamd_fold_encode(curve_id, _ptr(out), _ptr(p), num_partials, num_outputs)
     return out
 
 

@@ -116,12 +116,13 @@ enum class generator_source { host_api, builtin };
 // the Pedersen path of all five entry points
 void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequences,
                          const sxt_sequence_descriptor* descriptors, const void* generators,
-                         generator_source source, u64 offset_generators) {
+                         generator_source source, u64 offset_generators,
+                         bool projective_out = false) {
   if (num_sequences == 0) return; // reference: returns before touching anything
   BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
   api_state& st = state();
   checked_columns cc = check_descriptors(descriptors, num_sequences);
-  const u32 out_stride = static_cast<u32>(vt.output_size);
+  const u32 out_stride = static_cast<u32>(projective_out ? vt.projective_size : vt.output_size);
 
   if (st.backend == SXT_CPU_BACKEND) {
     std::vector<ed_point> builtin;
@@ -131,7 +132,7 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
       host_builtin_generators(st, builtin.data(), cc.longest, offset_generators);
       gens = builtin.data();
     }
-    vt.msm_host(static_cast<u8*>(commitments), out_stride, false, cc.cols, gens, false,
+    vt.msm_host(static_cast<u8*>(commitments), out_stride, projective_out, cc.cols, gens, false,
                 cc.longest);
     return;
   }
@@ -172,7 +173,8 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
     d_addends = d;
   }
   u8* d_out = st.io.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
-  vt.msm(*st.ctx, d_out, out_stride, false, cc.cols, d_addends, d_api_generators, st.stream);
+  vt.msm(*st.ctx, d_out, out_stride, projective_out, cc.cols, d_addends, d_api_generators,
+         st.stream);
   BZ_HIP_CHECK(hipMemcpyAsync(commitments, d_out, static_cast<size_t>(out_stride) * num_sequences,
                               hipMemcpyDeviceToHost, st.stream));
   BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
@@ -551,20 +553,66 @@ void bzamd_reset_for_testing(void) {
   g_state = nullptr;
 }
 
-void bzamd_msm_device(unsigned curve_id, void* commitments, uint32_t num_sequences,
-                      const struct sxt_sequence_descriptor* descriptors, const void* generators,
-                      void* stream) {
+namespace {
+void msm_device(unsigned curve_id, void* out, uint32_t num_sequences,
+                const struct sxt_sequence_descriptor* descriptors, const void* generators,
+                void* stream, bool projective_out) {
   if (num_sequences == 0) return;
   const curve_vtable* vt = curve_vtable_for(curve_id);
   BZ_RELEASE_ASSERT(vt != nullptr, "unknown curve id");
-  BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
+  BZ_RELEASE_ASSERT(out != nullptr, "output is null");
   BZ_RELEASE_ASSERT(generators != nullptr, "generators is null");
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
   checked_columns cc = check_descriptors(descriptors, num_sequences);
-  vt->msm(*st.context_for_current_device(), static_cast<u8*>(commitments),
-          static_cast<u32>(vt->output_size), false, cc.cols, nullptr, generators,
-          static_cast<hipStream_t>(stream));
+  vt->msm(*st.context_for_current_device(), static_cast<u8*>(out),
+          static_cast<u32>(projective_out ? vt->projective_size : vt->output_size), projective_out,
+          cc.cols, nullptr, generators, static_cast<hipStream_t>(stream));
+}
+} // namespace
+
+void bzamd_msm_device(unsigned curve_id, void* commitments, uint32_t num_sequences,
+                      const struct sxt_sequence_descriptor* descriptors, const void* generators,
+                      void* stream) {
+  msm_device(curve_id, commitments, num_sequences, descriptors, generators, stream, false);
+}
+
+void bzamd_msm_device_projective(unsigned curve_id, void* res, uint32_t num_sequences,
+                                 const struct sxt_sequence_descriptor* descriptors,
+                                 const void* generators, void* stream) {
+  msm_device(curve_id, res, num_sequences, descriptors, generators, stream, true);
+}
+
+void bzamd_msm_projective(unsigned curve_id, void* res, uint32_t num_sequences,
+                          const struct sxt_sequence_descriptor* descriptors,
+                          const void* generators) {
+  const curve_vtable* vt = curve_vtable_for(curve_id);
+  BZ_RELEASE_ASSERT(vt != nullptr, "unknown curve id");
+  BZ_RELEASE_ASSERT(num_sequences == 0 || generators != nullptr, "generators is null");
+  compute_commitments(*vt, res, num_sequences, descriptors, generators, generator_source::host_api,
+                      0, true);
+}
+
+void bzamd_fold_encode(unsigned curve_id, void* commitments, const void* partials,
+                       uint32_t num_partials, uint32_t num_outputs) {
+  const curve_vtable* vt = curve_vtable_for(curve_id);
+  BZ_RELEASE_ASSERT(vt != nullptr, "unknown curve id");
+  if (num_outputs == 0) return;
+  BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
+  BZ_RELEASE_ASSERT(num_partials == 0 || partials != nullptr, "partials is null");
+  vt->fold_encode_host(static_cast<u8*>(commitments), partials, num_partials, num_outputs);
+}
+
+void bzamd_fold_encode_device(unsigned curve_id, void* commitments, const void* partials,
+                              uint32_t num_partials, uint32_t num_outputs, void* stream) {
+  const curve_vtable* vt = curve_vtable_for(curve_id);
+  BZ_RELEASE_ASSERT(vt != nullptr, "unknown curve id");
+  if (num_outputs == 0) return;
+  BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
+  BZ_RELEASE_ASSERT(num_partials == 0 || partials != nullptr, "partials is null");
+  vt->fold_encode_device(static_cast<u8*>(commitments), partials, num_partials, num_outputs,
+                         static_cast<hipStream_t>(stream));
+  g_kernel_launches += 1;
 }
 
 struct bzamd_generators* bzamd_generators_new_device(unsigned curve_id, const void* generators,

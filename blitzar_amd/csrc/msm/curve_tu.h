@@ -18,6 +18,21 @@ __global__ void __launch_bounds__(256)
   addends[i] = C::addend_from_point(points[i]);
 }
 
+// commitments[k] = canonical encoding of sum_r partials[r * num_outputs + k]: the fold of the
+// per-rank partial results of a row-sharded MSM (SURVEY 8(e) way 2); one lane per output
+template <class C>
+__global__ void __launch_bounds__(64)
+    k_fold_encode(u8* __restrict__ out, const typename C::point* __restrict__ partials,
+                  u32 num_partials, u32 num_outputs) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_outputs) return;
+  typename C::point acc = C::identity();
+  for (u32 r = 0; r < num_partials; ++r) {
+    acc = C::add(acc, partials[static_cast<u64>(r) * num_outputs + k]);
+  }
+  C::encode(out + static_cast<u64>(k) * C::output_size, acc);
+}
+
 template <class C> struct curve_tu {
   static void msm(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                   const std::vector<host_column>& cols, const void* d_addends,
@@ -51,6 +66,24 @@ template <class C> struct curve_tu {
     }
     msm_host<C>(out, out_stride, projective_out, cols, addends.data());
   }
+  static void fold_encode_host(u8* out, const void* partials, u32 num_partials, u32 num_outputs) {
+    const auto* p = static_cast<const typename C::point*>(partials);
+    for (u32 k = 0; k < num_outputs; ++k) {
+      typename C::point acc = C::identity();
+      for (u32 r = 0; r < num_partials; ++r) {
+        acc = C::add(acc, p[static_cast<u64>(r) * num_outputs + k]);
+      }
+      C::encode(out + static_cast<u64>(k) * C::output_size, acc);
+    }
+  }
+  static void fold_encode_device(u8* d_out, const void* d_partials, u32 num_partials,
+                                 u32 num_outputs, hipStream_t stream) {
+    if (num_outputs == 0) return;
+    hipLaunchKernelGGL((k_fold_encode<C>), dim3(ceil_div_u32(num_outputs, 64)), dim3(64), 0, stream,
+                       d_out, static_cast<const typename C::point*>(d_partials), num_partials,
+                       num_outputs);
+    BZ_HIP_CHECK(hipGetLastError());
+  }
   static const curve_vtable& vtable() {
     static const curve_vtable vt{C::curve_id,
                                  C::api_generator_size,
@@ -61,6 +94,8 @@ template <class C> struct curve_tu {
                                  &curve_tu::prepare_addends,
                                  &curve_tu::prepare_addends_projective,
                                  &curve_tu::msm_host_entry,
+                                 &curve_tu::fold_encode_host,
+                                 &curve_tu::fold_encode_device,
                                  sizeof(typename compact_ops<C>::compact),
                                  &write_partition_table<C>,
                                  &read_partition_generators<C>};

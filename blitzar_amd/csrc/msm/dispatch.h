@@ -32,6 +32,10 @@ struct curve_vtable {
   void (*msm_host)(u8* out, u32 out_stride, bool projective_out,
                    const std::vector<host_column>& cols, const void* generators,
                    bool generators_projective, u64 num_generators);
+  // canonical encodings of the sums of `num_partials` projective partial results per output
+  void (*fold_encode_host)(u8* out, const void* partials, u32 num_partials, u32 num_outputs);
+  void (*fold_encode_device)(u8* d_out, const void* d_partials, u32 num_partials, u32 num_outputs,
+                             hipStream_t stream);
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
   void (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);

@@ -50,6 +50,26 @@ void bzamd_msm_device(unsigned curve_id, void* commitments, uint32_t num_sequenc
                       const struct sxt_sequence_descriptor* descriptors, const void* generators,
                       void* stream);
 
+/* Row-sharded MSM support (one column split by rows across GPUs):
+ * the partial result of a shard as a raw projective element (sxt_ristretto255 160 B /
+ * sxt_bls12_381_g1_p2 144 B / sxt_bn254_g1_p2, sxt_grumpkin_p2 96 B per column), and the fold
+ *   commitments[k] = canonical encoding of  sum_r partials[r * num_outputs + k]
+ * that every rank applies after the all-gather of the partials (RCCL has no user-defined
+ * reduction; group addition is exact, so the canonical result equals the unsharded one). */
+void bzamd_msm_device_projective(unsigned curve_id, void* res, uint32_t num_sequences,
+                                 const struct sxt_sequence_descriptor* descriptors,
+                                 const void* generators, void* stream);
+/* HOST operands, either backend (blocking) */
+void bzamd_msm_projective(unsigned curve_id, void* res, uint32_t num_sequences,
+                          const struct sxt_sequence_descriptor* descriptors,
+                          const void* generators);
+/* HOST operands (no backend needed: G - 1 point additions and one encoding per output) */
+void bzamd_fold_encode(unsigned curve_id, void* commitments, const void* partials,
+                       uint32_t num_partials, uint32_t num_outputs);
+/* DEVICE operands (async) */
+void bzamd_fold_encode_device(unsigned curve_id, void* commitments, const void* partials,
+                              uint32_t num_partials, uint32_t num_outputs, void* stream);
+
 /* Resident generator set: generators converted once into the engine's addend layout and kept in
  * HBM across calls. */
 struct bzamd_generators;

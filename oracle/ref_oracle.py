@@ -135,6 +135,32 @@ def add_projective(curve_id, a, b):
     return out
 
 
+def double_projective(curve_id, a):
+    pfx, nl, _, _ = CURVES[curve_id]
+    if curve_id == 0:
+        out = np.zeros(20, dtype=np.uint64)
+        lib().ref_c25519_double(_p(out), _p(np.ascontiguousarray(a)))
+        return out
+    out = np.zeros(3 * nl, dtype=np.uint64)
+    getattr(lib(), f"ref_{pfx}_double_p2")(_p(out), _p(np.ascontiguousarray(a)))
+    return out
+
+
+def affine_to_projective(curve_id, affine_bytes):
+    """C-ABI affine generator(s) -> projective element_p2 words (Z = R, identity = (0, R, 0))"""
+    _, nl, stride, _ = CURVES[curve_id]
+    a = np.ascontiguousarray(affine_bytes, dtype=np.uint8).reshape(-1, stride)
+    one = identity_affine(curve_id)[8 * nl:16 * nl].view(np.uint64)
+    out = np.zeros((a.shape[0], 3 * nl), dtype=np.uint64)
+    for i in range(a.shape[0]):
+        if a[i, 16 * nl]:
+            out[i, nl:2 * nl] = one
+        else:
+            out[i, :2 * nl] = a[i, :16 * nl].view(np.uint64)
+            out[i, 2 * nl:] = one
+    return out
+
+
 def ristretto_compress(p3):
     out = np.zeros(32, dtype=np.uint8)
     lib().ref_c25519_compress(_p(out), _p(np.ascontiguousarray(p3)))

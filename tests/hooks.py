@@ -1,0 +1,161 @@
+"""ctypes view of tests/native/_build/libbz_hooks.so: the product's header-only field / curve /
+recoding / planning code compiled for the host, so CPU tests can compare it limb-for-limb with
+the reference oracle.  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "hooks.cpp")
+LIB = os.path.join(ROOT, "tests", "native", "_build", "libbz_hooks.so")
+
+_lib = None
+
+
+def _newest_header():
+    newest = os.path.getmtime(SRC)
+    for d, _, fs in os.walk(os.path.join(ROOT, "blitzar_amd", "csrc")):
+        for f in fs:
+            if f.endswith(".h"):
+                newest = max(newest, os.path.getmtime(os.path.join(d, f)))
+    return newest
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        have_cxx = subprocess.run(["which", "g++"], capture_output=True).returncode == 0
+        if have_cxx and (not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest_header()):
+            os.makedirs(os.path.dirname(LIB), exist_ok=True)
+            subprocess.run(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-I" + ROOT, SRC, "-o",
+                            LIB], check=True)
+        _lib = ctypes.CDLL(LIB)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype=np.uint64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def f51(op, *args):
+    out = np.zeros(5, np.uint64)
+    getattr(lib(), f"bz_f51_{op}")(_p(out), *[_p(_c(a)) for a in args])
+    return out
+
+
+def ed_base_elements(first, n):
+    out = np.zeros((n, 20), np.uint64)
+    lib().bz_ed_base_elements(_p(out), ctypes.c_uint64(first), ctypes.c_uint64(n))
+    return out
+
+
+def ed_add(a, b):
+    out = np.zeros(20, np.uint64)
+    lib().bz_ed_add(_p(out), _p(_c(a)), _p(_c(b)))
+    return out
+
+
+def ed_sub(a, b):
+    out = np.zeros(20, np.uint64)
+    lib().bz_ed_sub_cached(_p(out), _p(_c(a)), _p(_c(b)))
+    return out
+
+
+def ed_dbl(a, k=None):
+    out = np.zeros(20, np.uint64)
+    if k is None:
+        lib().bz_ed_dbl(_p(out), _p(_c(a)))
+    else:
+        lib().bz_ed_dbl_n(_p(out), _p(_c(a)), ctypes.c_int(k))
+    return out
+
+
+def ed_neg(a):
+    out = np.zeros(20, np.uint64)
+    lib().bz_ed_neg(_p(out), _p(_c(a)))
+    return out
+
+
+def ristretto_encode(p):
+    out = np.zeros(32, np.uint8)
+    lib().bz_ristretto_encode(_p(out), _p(_c(p)))
+    return out
+
+
+def ristretto_decode(s):
+    out = np.zeros(20, np.uint64)
+    rc = lib().bz_ristretto_decode(_p(out), _p(_c(s, np.uint8)))
+    assert rc == 0, "not a canonical ristretto255 encoding"
+    return out
+
+
+PFX = {1: "bls12_381", 2: "bn254", 3: "grumpkin"}
+LIMBS = {1: 6, 2: 4, 3: 4}
+
+
+def sw_field_mul(cid, f, g):
+    out = np.zeros(LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_field_mul")(_p(out), _p(_c(f)), _p(_c(g)))
+    return out
+
+
+def sw_field_addsub(cid, f, g):
+    s = np.zeros(LIMBS[cid], np.uint64)
+    d = np.zeros(LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_field_addsub")(_p(s), _p(d), _p(_c(f)), _p(_c(g)))
+    return s, d
+
+
+def sw_add(cid, a, b):
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_add")(_p(out), _p(_c(a)), _p(_c(b)))
+    return out
+
+
+def sw_add_mixed(cid, a, b_affine_xy):
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_add_mixed")(_p(out), _p(_c(a)), _p(_c(b_affine_xy)))
+    return out
+
+
+def sw_dbl(cid, a):
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_dbl")(_p(out), _p(_c(a)))
+    return out
+
+
+def sw_to_affine(cid, a):
+    out = np.zeros(2 * LIMBS[cid], np.uint64)
+    inf = getattr(lib(), f"bz_{PFX[cid]}_to_affine")(_p(out), _p(_c(a)))
+    return out, bool(inf)
+
+
+def bls_compress(a):
+    out = np.zeros(48, np.uint8)
+    lib().bz_bls12_381_compress(_p(out), _p(_c(a)))
+    return out
+
+
+def recode(row_bytes, bit_offset, bit_width, is_signed, window_bits, num_windows):
+    row = np.zeros(len(row_bytes) + 40, np.uint8)  # the recoder may read a few bytes past the field
+    row[:len(row_bytes)] = row_bytes
+    digits = np.zeros(num_windows, np.int32)
+    lib().bz_recode(_p(digits), _p(row), ctypes.c_uint32(bit_offset), ctypes.c_uint32(bit_width),
+                    ctypes.c_int(1 if is_signed else 0), ctypes.c_uint32(window_bits),
+                    ctypes.c_uint32(num_windows))
+    return digits
+
+
+def plan(ns, bit_widths, signed, max_window_bits=16):
+    k = len(ns)
+    per = np.zeros((k, 4), np.uint32)
+    totals = np.zeros(5, np.uint64)
+    lib().bz_plan(_p(per), _p(totals), _p(_c(ns)), _p(_c(bit_widths, np.uint32)),
+                  _p(_c(signed, np.int32)), ctypes.c_uint32(k), ctypes.c_uint32(max_window_bits))
+    return per, totals

@@ -5,6 +5,8 @@
 
 #include "blitzar_amd/csrc/curve/ed25519.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
+#include "blitzar_amd/csrc/msm/plan.h"
+#include "blitzar_amd/csrc/msm/recode.h"
 
 using namespace bz;
 
@@ -139,5 +141,41 @@ void bz_bls12_381_compress(u8* out48, const u64* a) {
   bls12_381_g1::point p;
   std::memcpy(&p, a, sizeof(p));
   bls12_381_g1_compress(out48, p);
+}
+
+// signed radix-2^c digits of one scalar bit field (msm/recode.h); returns the number of digits
+int bz_recode(int* digits, const u8* row, u32 bit_offset, u32 bit_width, int is_signed,
+              u32 window_bits, u32 num_windows) {
+  digit_recoder rec;
+  rec.init(row, bit_offset, bit_width, is_signed != 0, window_bits);
+  for (u32 w = 0; w < num_windows; ++w) digits[w] = rec.next();
+  return static_cast<int>(num_windows);
+}
+
+// planner (msm/plan.h): per column {window_bits, num_windows, num_groups, rows_per_group};
+// totals {tasks, total_buckets, total_entries, max_task_rows}
+void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, const int* is_signed,
+             u32 num_columns, u32 max_window_bits) {
+  std::vector<host_column> cols(num_columns);
+  for (u32 i = 0; i < num_columns; ++i) {
+    cols[i] = host_column{nullptr, n[i], (bit_width[i] + 7) / 8, 0, bit_width[i], is_signed[i] != 0};
+  }
+  msm_tuning tune;
+  tune.max_window_bits = max_window_bits;
+  msm_plan plan = make_msm_plan(cols, tune);
+  for (u32 i = 0; i < num_columns; ++i) {
+    per_column[4 * i + 0] = plan.columns[i].window_bits;
+    per_column[4 * i + 1] = plan.columns[i].num_windows;
+    per_column[4 * i + 2] = plan.columns[i].num_groups;
+    per_column[4 * i + 3] = plan.columns[i].rows_per_group;
+  }
+  totals[0] = plan.tasks.size();
+  totals[1] = plan.total_buckets;
+  totals[2] = plan.total_entries;
+  totals[3] = plan.max_task_rows;
+  // every row of every column is covered exactly once per window
+  u64 covered = 0;
+  for (const auto& t : plan.tasks) covered += t.row_count;
+  totals[4] = covered;
 }
 }

@@ -1,0 +1,106 @@
+"""Fixed-base handles (sxt_multiexp_handle_*, sxt_fixed_*multiexponentiation) on the host
+backend, through the C ABI, against the fixed-base oracle (oracle/fixed_base.py over oracle/_ref)
+and the golden fixtures.  Results are projective and not canonical in the reference either
+(cbindings/fixed_pedersen.t.cc:63,133-134 compares with projective ==), so both sides are
+canonicalised before the byte comparison."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "msm_golden.npz"))
+
+
+def canon(oracle, cid, res):
+    words = res.view(np.uint64).reshape(res.shape[0], -1)
+    return np.stack([oracle.canonical(cid, p).view(np.uint8).reshape(-1) for p in words])
+
+
+def projective_generators(oracle, cid, n):
+    gens = util.generators_for(cid, n)
+    return gens if cid == 0 else oracle.affine_to_projective(cid, gens)
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_golden_packed(cpu_backend, oracle, cid):
+    proj = GOLDEN[f"curve{cid}_fixed_projective_generators"]
+    h = cpu_backend.MultiexpHandle(cid, proj)
+    res = h.packed_multiexponentiation(GOLDEN["fixed_bit_table"], proj.shape[0],
+                                       GOLDEN[f"curve{cid}_fixed_scalars"])
+    assert np.array_equal(canon(oracle, cid, res), GOLDEN[f"curve{cid}_fixed_canonical"])
+    h.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_plain_packed_vlen_match_oracle(cpu_backend, oracle, cid):
+    from oracle import fixed_base
+    rng = np.random.default_rng(300 + cid)
+    n = 37
+    proj = projective_generators(oracle, cid, n)
+    table = fixed_base.PartitionTable(cid, proj, 4)
+    h = cpu_backend.MultiexpHandle(cid, proj)
+    # plain: 3 outputs of 2 bytes
+    s = rng.integers(0, 256, (n, 6), dtype=np.uint8)
+    got = h.multiexponentiation(2, 3, n, s)
+    want = fixed_base.multiexponentiate_bytes(table, 2, 3, n, s)
+    assert np.array_equal(canon(oracle, cid, got), canon(oracle, cid, want))
+    # packed: odd widths, a 256-bit output, fewer rows than generators
+    bt = [1, 7, 9, 33, 256, 2]
+    m = 29
+    s = rng.integers(0, 256, (m, (sum(bt) + 7) // 8), dtype=np.uint8)
+    got = h.packed_multiexponentiation(bt, m, s)
+    want = fixed_base.multiexponentiate(table, bt, m, s)
+    assert np.array_equal(canon(oracle, cid, got), canon(oracle, cid, want))
+    # vlen: ascending lengths with a zero-length output
+    bt, lengths = [4, 12, 1, 64], [0, 5, 5, 37]
+    s = rng.integers(0, 256, (n, (sum(bt) + 7) // 8), dtype=np.uint8)
+    got = h.vlen_multiexponentiation(bt, lengths, s)
+    want = fixed_base.multiexponentiate(table, bt, n, s, lengths)
+    assert np.array_equal(canon(oracle, cid, got), canon(oracle, cid, want))
+    h.close()
+
+
+def test_known_answers_of_the_reference_tests(cpu_backend, oracle):
+    """cbindings/fixed_pedersen.t.cc:51-200"""
+    g = oracle.ristretto_generators(3, 7)
+
+    def lin(coeffs):
+        return oracle.commit(0, [(np.array(coeffs, dtype=np.uint64), False)], g)[0]
+
+    h = cpu_backend.MultiexpHandle(0, g[:2])
+    r = h.multiexponentiation(2, 1, 2, np.array([1, 0, 0, 2], np.uint8))
+    assert np.array_equal(canon(oracle, 0, r)[0], lin([1, 512]))
+    r = h.packed_multiexponentiation([3, 1], 2, np.array([0b1010, 0b0101], np.uint8))
+    assert np.array_equal(canon(oracle, 0, r), np.stack([lin([2, 5]), lin([1, 0])]))
+    r = h.vlen_multiexponentiation([3, 1], [1, 2], np.array([0b1011, 0b1101], np.uint8))
+    assert np.array_equal(canon(oracle, 0, r), np.stack([lin([3, 0]), lin([1, 1])]))
+    h.close()
+    h = cpu_backend.MultiexpHandle(0, g)
+    r = h.packed_multiexponentiation([8], 3, np.array([1, 1, 1], np.uint8))
+    assert np.array_equal(canon(oracle, 0, r)[0], lin([1, 1, 1]))
+    h.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_partition_table_file_interop(cpu_backend, oracle, cid, tmp_path, monkeypatch):
+    """sxt_multiexp_handle_write_to_file writes the reference's table format byte for byte
+    (in_memory_partition_table_accessor.h:42-59,98-105) and _new_from_file reads it back"""
+    from oracle import fixed_base
+    monkeypatch.setenv("BLITZAR_PARTITION_WINDOW_WIDTH", "4")
+    proj = GOLDEN[f"curve{cid}_fixed_projective_generators"]  # 11 generators -> padded to 12
+    h = cpu_backend.MultiexpHandle(cid, proj)
+    path = str(tmp_path / f"table{cid}.bin")
+    h.write_to_file(path)
+    h.close()
+    with open(path, "rb") as fh:
+        data = fh.read()
+    want = fixed_base.PartitionTable(cid, proj, 4).file_bytes()
+    assert data == want
+    h2 = cpu_backend.MultiexpHandle(cid, filename=path)
+    n = proj.shape[0]
+    res = h2.packed_multiexponentiation(GOLDEN["fixed_bit_table"], n,
+                                        GOLDEN[f"curve{cid}_fixed_scalars"])
+    assert np.array_equal(canon(oracle, cid, res), GOLDEN[f"curve{cid}_fixed_canonical"])
+    h2.close()

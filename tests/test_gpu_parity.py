@@ -95,3 +95,143 @@ def test_null_and_empty_inputs(gpu_backend):
     # zero-length sequences commit to the identity encoding
     out = api.compute_pedersen_commitments(0, [(np.zeros((0, 4), np.uint8), False)])
     assert out.tolist() == [[0] * 32]
+
+
+#--------------------------------------------------------------------------------------------------
+# committed golden fixtures (generated from the reference by tests/golden/make_golden.py)
+#--------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+from tests.golden import make_golden  # noqa: E402
+
+GOLDEN_NPZ = np.load(os.path.join(os.path.dirname(__file__), "golden", "msm_golden.npz"))
+
+
+@pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
+def test_golden_commitments(gpu_backend, curve_id):
+    cols = make_golden.golden_columns(1000 + curve_id, 48)
+    got = gpu_backend.compute_pedersen_commitments(
+        curve_id, cols, generators=GOLDEN_NPZ[f"curve{curve_id}_generators"])
+    assert np.array_equal(got, GOLDEN_NPZ[f"curve{curve_id}_commitments"])
+
+
+def _canon(oracle, cid, res):
+    words = res.view(np.uint64).reshape(res.shape[0], -1)
+    return np.stack([oracle.canonical(cid, p).view(np.uint8).reshape(-1) for p in words])
+
+
+@pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
+def test_fixed_base_golden_and_file_roundtrip(gpu_backend, oracle, curve_id, tmp_path):
+    proj = GOLDEN_NPZ[f"curve{curve_id}_fixed_projective_generators"]
+    before = gpu_backend.load().bzamd_kernel_launch_count()
+    h = gpu_backend.MultiexpHandle(curve_id, proj)
+    res = h.packed_multiexponentiation(GOLDEN_NPZ["fixed_bit_table"], proj.shape[0],
+                                       GOLDEN_NPZ[f"curve{curve_id}_fixed_scalars"])
+    assert gpu_backend.load().bzamd_kernel_launch_count() > before
+    assert np.array_equal(_canon(oracle, curve_id, res),
+                          GOLDEN_NPZ[f"curve{curve_id}_fixed_canonical"])
+    path = str(tmp_path / "t.bin")
+    h.write_to_file(path)
+    h.close()
+    h2 = gpu_backend.MultiexpHandle(curve_id, filename=path)
+    res = h2.packed_multiexponentiation(GOLDEN_NPZ["fixed_bit_table"], proj.shape[0],
+                                        GOLDEN_NPZ[f"curve{curve_id}_fixed_scalars"])
+    assert np.array_equal(_canon(oracle, curve_id, res),
+                          GOLDEN_NPZ[f"curve{curve_id}_fixed_canonical"])
+    h2.close()
+
+
+@pytest.mark.parametrize("curve_id", [0, 3])
+def test_fixed_base_plain_packed_vlen_match_oracle(gpu_backend, oracle, curve_id):
+    from oracle import fixed_base
+    rng = np.random.default_rng(900 + curve_id)
+    n = 300
+    gens = util.generators_for(curve_id, n)
+    proj = gens if curve_id == 0 else oracle.affine_to_projective(curve_id, gens)
+    h = gpu_backend.MultiexpHandle(curve_id, proj)
+    # mixed 8 / 32 / 256-bit outputs (BASELINE configs[4] shape), checked against the
+    # variable-base reference backend on the unpacked columns
+    bt = [8, 32, 256] * 4
+    s = rng.integers(0, 256, (n, (sum(bt) + 7) // 8), dtype=np.uint8)
+    got = _canon(oracle, curve_id, h.packed_multiexponentiation(bt, n, s))
+    want = oracle.commit(curve_id, fixed_base.unpack_columns(bt, n, s), gens)
+    assert np.array_equal(got[:, :want.shape[1]], want)
+    bt, lengths = [4, 12, 1, 64], [0, 5, 5, n]
+    s = rng.integers(0, 256, (n, (sum(bt) + 7) // 8), dtype=np.uint8)
+    got = _canon(oracle, curve_id, h.vlen_multiexponentiation(bt, lengths, s))
+    want = oracle.commit(curve_id, fixed_base.unpack_columns(bt, n, s, lengths), gens)
+    assert np.array_equal(got[:, :want.shape[1]], want)
+    s = rng.integers(0, 256, (n, 6), dtype=np.uint8)
+    got = _canon(oracle, curve_id, h.multiexponentiation(2, 3, n, s))
+    want = oracle.commit(curve_id, fixed_base.unpack_columns([16] * 3, n, s), gens)
+    assert np.array_equal(got[:, :want.shape[1]], want)
+    h.close()
+
+
+#--------------------------------------------------------------------------------------------------
+# BASELINE sizes through size-independent properties (the oracle needs ~80 s for one 2^20 column)
+#--------------------------------------------------------------------------------------------------
+def test_full_size_properties_curve25519_n2_20(gpu_backend):
+    """n = 2^20 (BASELINE configs[1]):
+      * all-ones column == compress(one_commit(n))  (prefix sum of the built-in generators),
+      * linearity: commit(a) + commit(b) == commit(a + b) with 252-bit a, b,
+      * a column and its two halves (second half against offset generators) agree,
+      * skewed data (every scalar equal) == scalar * one_commit."""
+    from tests import hooks
+    api = gpu_backend
+    n = 1 << 20
+    rng = np.random.default_rng(2020)
+    ones = np.ones((n, 1), np.uint8)
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x0f
+    b[:, 31] &= 0x0f
+    # a + b as 256-bit little-endian integers (fits: both < 2^252)
+    wa = a.view("<u8").astype(object)
+    wb = b.view("<u8").astype(object)
+    carry = np.zeros(n, dtype=object)
+    s = np.zeros((n, 4), dtype=np.uint64)
+    for k in range(4):
+        t = wa[:, k] + wb[:, k] + carry
+        s[:, k] = (t & 0xFFFFFFFFFFFFFFFF).astype(np.uint64)
+        carry = t >> 64
+    ab = s.view(np.uint8).reshape(n, 32)
+    same = np.tile(a[:1], (n, 1))
+    out = api.compute_pedersen_commitments(0, [(ones, False), (a, False), (b, False), (ab, False),
+                                               (same, False)])
+    one_commit = api.get_one_commit(n)
+    assert np.array_equal(out[0], hooks.ristretto_encode(one_commit))
+    pa, pb = hooks.ristretto_decode(out[1]), hooks.ristretto_decode(out[2])
+    assert np.array_equal(hooks.ristretto_encode(hooks.ed_add(pa, pb)), out[3])
+    lo = api.compute_pedersen_commitments(0, [(a[:n // 2], False)])
+    hi = api.compute_pedersen_commitments(0, [(a[n // 2:], False)], offset_generators=n // 2)
+    both = hooks.ed_add(hooks.ristretto_decode(lo[0]), hooks.ristretto_decode(hi[0]))
+    assert np.array_equal(hooks.ristretto_encode(both), out[1])
+    # scalar * one_commit by double-and-add on the host hooks
+    k = int.from_bytes(a[0].tobytes(), "little")
+    acc = api.get_one_commit(0)  # identity
+    for bit in range(k.bit_length() - 1, -1, -1):
+        acc = hooks.ed_dbl(acc)
+        if (k >> bit) & 1:
+            acc = hooks.ed_add(acc, one_commit)
+    assert np.array_equal(hooks.ristretto_encode(acc), out[4])
+
+
+def test_row_sharded_fold_on_device(gpu_backend, oracle):
+    """the single-GPU half of the row-sharded path: projective partials of two row ranges folded
+    and canonicalised == the unsharded commitment"""
+    import ctypes
+    api = gpu_backend
+    rng = np.random.default_rng(11)
+    for curve_id in (0, 2):
+        n = 5000
+        gens = util.generators_for(curve_id, n)
+        g = util.api_generators(curve_id, gens)
+        cols = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False),
+                (rng.integers(0, 256, (n, 8), dtype=np.uint8), True)]
+        parts = []
+        for lo, hi in ((0, 1700), (1700, n)):
+            parts.append(api.msm_projective(curve_id, [(c[lo:hi], s) for c, s in cols], g[lo:hi]))
+        got = api.fold_encode(curve_id, np.stack(parts))
+        assert np.array_equal(got, oracle.commit(curve_id, cols, gens))
+        _ = ctypes
