@@ -52,11 +52,22 @@ def _compile(src, newest_header, force):
     return obj, True
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, only=None):
+    """`only`: development shortcut -- recompile just the sources whose name contains one of the
+    given substrings and relink against the existing objects of the others (valid while the
+    cross-TU interface, msm/dispatch.h, is unchanged)."""
     os.makedirs(OUT, exist_ok=True)
     newest = max(os.path.getmtime(h) for h in _headers() + [os.path.abspath(__file__)])
+
+    def job(src):
+        if only is not None and not any(tag in src for tag in only):
+            obj = os.path.join(OUT, src.replace("/", "_").replace(".hip", ".o"))
+            assert os.path.exists(obj), f"--only needs an existing {obj}"
+            return obj, False
+        return _compile(src, newest, force or only is not None)
+
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        results = list(ex.map(lambda s: _compile(s, newest, force), SOURCES))
+        results = list(ex.map(job, SOURCES))
     objs = [o for o, _ in results]
     if force or any(c for _, c in results) or not os.path.exists(LIB):
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
@@ -71,4 +82,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):
+            only = a[len("--only="):].split(",")
+    build(force="--force" in sys.argv, only=only)

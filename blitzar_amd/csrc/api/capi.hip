@@ -39,9 +39,11 @@ void init_host_generators(api_state& st, u64 n) {
   if (st.backend == SXT_GPU_BACKEND) {
     // derive on the device (reference K15), keep both the raw p3 copy (served by
     // sxt_ristretto255_get_generators) and the resident addends
+    BZ_RELEASE_ASSERT(curve25519_vtable().addend_size == sizeof(ed29_cached),
+                      "built-in generator cache and MSM engine disagree on the addend layout");
     ed_point* d_raw = nullptr;
     BZ_HIP_CHECK(hipMalloc(&d_raw, sizeof(ed_point) * n));
-    BZ_HIP_CHECK(hipMalloc(&st.d_builtin_addends, sizeof(ed_cached) * n));
+    BZ_HIP_CHECK(hipMalloc(&st.d_builtin_addends, sizeof(ed29_cached) * n));
     builtin_generators_enqueue(d_raw, 0, n, st.stream);
     g_kernel_launches += 1;
     curve25519_vtable().prepare_addends(st.d_builtin_addends, d_raw, n, st.stream);
@@ -167,7 +169,7 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
              st.d_builtin_addends != nullptr) {
     d_addends = st.d_builtin_addends + offset_generators;
   } else {
-    ed_cached* d = st.io.take<ed_cached>(cc.longest + 1);
+    ed29_cached* d = st.io.take<ed29_cached>(cc.longest + 1);
     builtin_addends_enqueue(d, offset_generators, cc.longest, st.stream);
     g_kernel_launches += 1;
     d_addends = d;

@@ -40,6 +40,7 @@ template <class C> struct compact_ops;
 template <> struct compact_ops<ed25519_msm> {
   using compact = ed_compact;
   using point = ed_point;
+  static point identity() { return ed::identity(); }
   static point expand(const compact& c) { return {c.X, c.Y, f51::one(), c.T}; }
   static compact shrink(const point& p) {
     fe51 zinv = f51::invert(p.Z);
@@ -81,6 +82,7 @@ template <class C> struct sw_compact_ops {
   using F = typename C::F;
   using compact = sw_compact<N>;
   using point = typename C::point;
+  static point identity() { return C::identity(); }
   static bool is_identity(const compact& c) { return c.X.v[N - 1] == ~u64{0}; }
   static point expand(const compact& c) {
     if (is_identity(c)) return C::identity();
@@ -109,9 +111,9 @@ template <> struct compact_ops<bls12_381_msm> : sw_compact_ops<bls12_381_msm> {}
 // one window slice: sums[m] for all 2^w masks; gens holds w projective generators
 template <class C>
 void partition_table_slice(typename compact_ops<C>::compact* sums, unsigned w,
-                           const typename C::point* gens) {
+                           const typename compact_ops<C>::point* gens) {
   using ops = compact_ops<C>;
-  sums[0] = ops::shrink(C::identity());
+  sums[0] = ops::shrink(ops::identity());
   for (unsigned i = 0; i < w; ++i) sums[1u << i] = ops::shrink(gens[i]);
   const u64 count = u64{1} << w;
   // entry m (>= 2 bits set) = entry[m without its lowest set bit] + entry[lowest set bit];
@@ -127,7 +129,7 @@ void partition_table_slice(typename compact_ops<C>::compact* sums, unsigned w,
 template <class C>
 void write_partition_table(std::FILE* f, unsigned w, const void* projective_generators, u64 n) {
   using ops = compact_ops<C>;
-  using point = typename C::point;
+  using point = typename ops::point; // the ABI's projective element
   const point* g = static_cast<const point*>(projective_generators);
   const u32 w32 = w;
   std::fwrite(&w32, sizeof(w32), 1, f);
@@ -137,7 +139,7 @@ void write_partition_table(std::FILE* f, unsigned w, const void* projective_gene
   for (u64 k = 0; k < windows; ++k) {
     for (unsigned i = 0; i < w; ++i) {
       const u64 idx = k * w + i;
-      slice[i] = idx < n ? g[idx] : C::identity();
+      slice[i] = idx < n ? g[idx] : ops::identity();
     }
     partition_table_slice<C>(sums.data(), w, slice.data());
     std::fwrite(sums.data(), sizeof(typename ops::compact), sums.size(), f);
@@ -148,7 +150,7 @@ void write_partition_table(std::FILE* f, unsigned w, const void* projective_gene
 template <class C>
 bool read_partition_generators(std::FILE* f, unsigned& w, std::vector<u8>& out, u64& n) {
   using ops = compact_ops<C>;
-  using point = typename C::point;
+  using point = typename ops::point;
   u32 w32 = 0;
   if (std::fread(&w32, sizeof(w32), 1, f) != 1 || w32 == 0 || w32 > 32) return false;
   w = w32;

@@ -5,11 +5,12 @@
 #pragma once
 
 #include "blitzar_amd/csrc/base/device.h"
-#include "blitzar_amd/csrc/curve/ed25519.h"
+#include "blitzar_amd/csrc/curve/ed29.h"
 
 namespace bz {
 // d_out[i] = g_{first + i} as raw extended coordinates (limb-identical to the reference)
 void builtin_generators_enqueue(ed_point* d_out, u64 first, u64 n, hipStream_t stream);
-// same, directly as resident addends (Y+X, Y-X, Z, 2dT)
-void builtin_addends_enqueue(ed_cached* d_out, u64 first, u64 n, hipStream_t stream);
+// same, directly as the MSM engine's resident addends (curve/ed29.h: (Y+X, Y-X, Z, 2dT) on the
+// 9 x 29-bit field)
+void builtin_addends_enqueue(ed29_cached* d_out, u64 first, u64 n, hipStream_t stream);
 } // namespace bz

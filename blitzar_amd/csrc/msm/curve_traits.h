@@ -7,6 +7,8 @@
 #pragma once
 
 #include "blitzar_amd/csrc/curve/ed25519.h"
+#include "blitzar_amd/csrc/curve/ed29.h"
+#include "blitzar_amd/csrc/curve/ed29_coop.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
 
 namespace bz {
@@ -22,33 +24,59 @@ template <int N> struct sw_api_affine {
 static_assert(sizeof(sw_api_affine<4>) == 72);
 static_assert(sizeof(sw_api_affine<6>) == 104);
 
+// curve25519: the kernels compute on the 9 x 29-bit representation (field/f29.h, curve/ed29.h);
+// the ABI's radix-2^51 element_p3 only appears where generators enter (make_addend) and where a
+// result leaves (encode / store_projective).
 struct ed25519_msm {
   static constexpr unsigned curve_id = 0;
-  using point = ed_point;
-  using addend = ed_cached;
+  using point = ed29_point;
+  using addend = ed29_cached;
+  using api_projective = ed_point; // sxt_ristretto255 / c21t::element_p3
   static constexpr size_t api_generator_size = 160; // sxt_ristretto255
   static constexpr size_t output_size = 32;         // sxt_ristretto255_compressed
   static constexpr size_t projective_size = 160;    // element_p3 (fixed-base results)
+  // register budget of k_accumulate: 3 waves per SIMD = at most 168 VGPRs (accumulator, current
+  // addend, prefetched next addend, product temporaries)
+  static constexpr int accumulate_waves_per_simd = 3;
 
-  BZ_HD static point identity() { return ed::identity(); }
-  BZ_HD static point add(const point& a, const point& b) { return ed::add(a, b); }
-  BZ_HD static point dbl_n(const point& a, int k) { return ed::dbl_n(a, k); }
-  BZ_HD static point neg(const point& a) { return ed::neg(a); }
+  BZ_HD static point identity() { return ed29::identity(); }
+  BZ_HD static point add(const point& a, const point& b) { return ed29::add(a, b); }
+  BZ_HD static point dbl_n(const point& a, int k) { return ed29::dbl_n(a, k); }
+  BZ_HD static point neg(const point& a) { return ed29::neg(a); }
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
-    acc = ed::to_point(negate ? ed::sub_cached(acc, q) : ed::add_cached(acc, q));
+    acc = ed29::add_cached(acc, q, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
-    const ed_point* g = static_cast<const ed_point*>(api_generators);
-    return ed::to_cached(g[i]);
+    return ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]);
   }
-  BZ_HD static addend addend_from_point(const point& p) { return ed::to_cached(p); }
-  BZ_HD static point point_from_api(const void* api_generators, u64 i) {
-    return static_cast<const ed_point*>(api_generators)[i];
+  // handle generators arrive as element_p3 too
+  BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {
+    return ed29::cached_from_ed(static_cast<const ed_point*>(projective)[i]);
   }
-  BZ_HD static void encode(u8* out, const point& p) { ristretto::encode(out, p); }
+  BZ_HD static void encode(u8* out, const point& p) { ristretto29::encode(out, p); }
   BZ_HD static void store_projective(u8* out, const point& p) {
-    *reinterpret_cast<point*>(out) = p;
+    *reinterpret_cast<ed_point*>(out) = ed29::to_ed(p);
   }
+  // ABI projective element -> engine point (fold of row-sharded partials)
+  BZ_HD static point point_from_api_projective(const void* projective, u64 i) {
+    return ed29::from_ed(static_cast<const ed_point*>(projective)[i]);
+  }
+  // k_combine's dependent chain, run by all 64 lanes of one wavefront with the four lanes of
+  // every DPP quad sharing each doubling / addition (curve/ed29_coop.h):
+  //   sum_w 2^(c w) * window_sums[w * stride]
+  static constexpr bool has_wave_horner = true;
+#if defined(__HIPCC__)
+  __device__ static point wave_horner(const point* window_sums, u32 stride, u32 num_windows,
+                                      u32 window_bits) {
+    const u32 role = threadIdx.x & 3;
+    point acc = window_sums[(num_windows - 1) * stride];
+    for (u32 wi = num_windows - 1; wi-- > 0;) {
+      for (u32 k = 0; k < window_bits; ++k) acc = ed29::dbl_coop4(acc, role);
+      acc = ed29::add_cached_coop4(acc, ed29::to_cached(window_sums[wi * stride]), role);
+    }
+    return acc;
+  }
+#endif
 };
 
 template <class G, unsigned CurveId> struct sw_msm_base {
@@ -57,9 +85,12 @@ template <class G, unsigned CurveId> struct sw_msm_base {
   using F = typename G::F;
   using point = typename G::point;
   using addend = typename G::affine; // (0, 0) marks the identity (never on y^2 = x^3 + b, b != 0)
+  using api_projective = point;      // sxt_*_p2 / element_p2
   using api_affine = sw_api_affine<N>;
   static constexpr size_t api_generator_size = sizeof(api_affine);
   static constexpr size_t projective_size = sizeof(point);
+  static constexpr int accumulate_waves_per_simd = 1;
+  static constexpr bool has_wave_horner = false;
 
   BZ_HD static point identity() { return G::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return G::add(a, b); }
@@ -87,6 +118,13 @@ template <class G, unsigned CurveId> struct sw_msm_base {
       a.y = F::zero();
     }
     return a;
+  }
+  // the ABI's projective element (element_p2) is the engine's point type for these curves
+  BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {
+    return addend_from_point(static_cast<const point*>(projective)[i]);
+  }
+  BZ_HD static point point_from_api_projective(const void* projective, u64 i) {
+    return static_cast<const point*>(projective)[i];
   }
   BZ_HD static point point_from_api(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];

@@ -12,23 +12,23 @@ namespace bz {
 template <class C>
 __global__ void __launch_bounds__(256)
     k_prepare_addends_projective(typename C::addend* __restrict__ addends,
-                                 const typename C::point* __restrict__ points, u64 n) {
+                                 const typename C::api_projective* __restrict__ points, u64 n) {
   const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  addends[i] = C::addend_from_point(points[i]);
+  addends[i] = C::addend_from_api_projective(points, i);
 }
 
 // commitments[k] = canonical encoding of sum_r partials[r * num_outputs + k]: the fold of the
 // per-rank partial results of a row-sharded MSM (SURVEY 8(e) way 2); one lane per output
 template <class C>
 __global__ void __launch_bounds__(64)
-    k_fold_encode(u8* __restrict__ out, const typename C::point* __restrict__ partials,
+    k_fold_encode(u8* __restrict__ out, const typename C::api_projective* __restrict__ partials,
                   u32 num_partials, u32 num_outputs) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num_outputs) return;
   typename C::point acc = C::identity();
   for (u32 r = 0; r < num_partials; ++r) {
-    acc = C::add(acc, partials[static_cast<u64>(r) * num_outputs + k]);
+    acc = C::add(acc, C::point_from_api_projective(partials, static_cast<u64>(r) * num_outputs + k));
   }
   C::encode(out + static_cast<u64>(k) * C::output_size, acc);
 }
@@ -52,7 +52,7 @@ template <class C> struct curve_tu {
     if (n == 0) return;
     hipLaunchKernelGGL((k_prepare_addends_projective<C>), dim3(ceil_div_u32(n, 256)), dim3(256), 0,
                        stream, static_cast<typename C::addend*>(d_addends),
-                       static_cast<const typename C::point*>(d_projective), n);
+                       static_cast<const typename C::api_projective*>(d_projective), n);
     BZ_HIP_CHECK(hipGetLastError());
   }
   static void msm_host_entry(u8* out, u32 out_stride, bool projective_out,
@@ -61,17 +61,17 @@ template <class C> struct curve_tu {
     std::vector<typename C::addend> addends(num_generators);
     for (u64 i = 0; i < num_generators; ++i) {
       addends[i] = generators_projective
-                       ? C::addend_from_point(static_cast<const typename C::point*>(generators)[i])
+                       ? C::addend_from_api_projective(generators, i)
                        : C::make_addend(generators, i);
     }
     msm_host<C>(out, out_stride, projective_out, cols, addends.data());
   }
   static void fold_encode_host(u8* out, const void* partials, u32 num_partials, u32 num_outputs) {
-    const auto* p = static_cast<const typename C::point*>(partials);
     for (u32 k = 0; k < num_outputs; ++k) {
       typename C::point acc = C::identity();
       for (u32 r = 0; r < num_partials; ++r) {
-        acc = C::add(acc, p[static_cast<u64>(r) * num_outputs + k]);
+        acc = C::add(acc,
+                     C::point_from_api_projective(partials, static_cast<u64>(r) * num_outputs + k));
       }
       C::encode(out + static_cast<u64>(k) * C::output_size, acc);
     }
@@ -80,7 +80,8 @@ template <class C> struct curve_tu {
                                  u32 num_outputs, hipStream_t stream) {
     if (num_outputs == 0) return;
     hipLaunchKernelGGL((k_fold_encode<C>), dim3(ceil_div_u32(num_outputs, 64)), dim3(64), 0, stream,
-                       d_out, static_cast<const typename C::point*>(d_partials), num_partials,
+                       d_out, static_cast<const typename C::api_projective*>(d_partials),
+                       num_partials,
                        num_outputs);
     BZ_HIP_CHECK(hipGetLastError());
   }

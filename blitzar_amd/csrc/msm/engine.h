@@ -75,11 +75,13 @@ inline msm_plan plan_for_columns(const std::vector<host_column>& cols, const msm
   return make_msm_plan(cols, t);
 }
 
-// one-time k_bucket_sort attribute: it needs up to 128 KiB + of dynamic LDS
-static void configure_sort_kernel() {
+// one-time kernel attributes: the sort kernels need up to 128 KiB of dynamic LDS
+static void configure_sort_kernels() {
   static bool done = false;
   if (done) return;
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_hist),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   done = true;
 }
@@ -93,7 +95,7 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   using point = typename C::point;
   using addend = typename C::addend;
   if (cols.empty()) return;
-  configure_sort_kernel();
+  configure_sort_kernels();
   const msm_plan plan = plan_for_columns(cols, ctx.tuning);
   const u32 num_tasks = static_cast<u32>(plan.tasks.size());
   const u32 num_cols = static_cast<u32>(plan.columns.size());
@@ -106,8 +108,12 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   if (d_addends == nullptr) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
   need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
   need += device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
+  need += device_arena::padded(sizeof(u32) * (plan.total_hist + 2));
+  need += device_arena::padded(sizeof(u32) * (plan.total_chunks + 1));
+  need += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
   need += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
+  need += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
   need += device_arena::padded(sizeof(point) * (static_cast<size_t>(num_tasks) * partial_stride + 1));
   ctx.arena.reset(need, stream);
 
@@ -135,8 +141,12 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     }
     i16* d_digits = ctx.arena.take<i16>(plan.total_entries + 8);
     u32* d_sorted = ctx.arena.take<u32>(plan.total_entries + 8);
+    u32* d_hist = ctx.arena.take<u32>(plan.total_hist + 2);
+    u32* d_chunk_totals = ctx.arena.take<u32>(plan.total_chunks + 1);
+    u32* d_segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
     u32* d_bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
     point* d_bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
+    point* d_heads = ctx.arena.take<point>(plan.total_segments + 1);
     point* d_partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * partial_stride + 1);
 
     mark(1);
@@ -144,32 +154,41 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
                        stream, d_digits, d_cols, d_tasks);
     mark(2);
 
+    // counting sort by bucket
+    BZ_HIP_CHECK(hipMemsetAsync(d_chunk_totals, 0, sizeof(u32) * (plan.total_chunks + 1), stream));
     const size_t sort_lds = sizeof(u32) * plan.max_task_buckets;
-    hipLaunchKernelGGL(k_bucket_sort, dim3(num_tasks), dim3(kSortThreads), sort_lds, stream,
-                       d_sorted, d_bucket_end, d_digits, d_tasks);
+    hipLaunchKernelGGL(k_bucket_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
+                       sort_lds, stream, d_hist, d_chunk_totals, d_digits, d_tasks);
+    hipLaunchKernelGGL(k_bucket_offsets,
+                       dim3(ceil_div_u32(plan.max_task_buckets, kOffsetChunkBuckets), num_tasks),
+                       dim3(256), 0, stream, d_hist, d_bucket_end, d_chunk_totals, d_tasks);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(plan.max_task_slices, num_tasks),
+                       dim3(kSortThreads), sort_lds, stream, d_sorted, d_segment_bucket, d_hist,
+                       d_digits, d_tasks);
     mark(3);
 
-    hipLaunchKernelGGL((k_accumulate<C>),
-                       dim3(ceil_div_u32(plan.max_task_buckets, kAccumulateThreads), num_tasks),
-                       dim3(kAccumulateThreads), 0, stream, d_bucket_sums, d_bucket_end, d_sorted,
+    const u32 seg_blocks =
+        ceil_div_u32(plan.max_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
+    hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
+                       stream, d_bucket_sums, d_heads, d_bucket_end, d_segment_bucket, d_sorted,
                        d_addends, d_tasks);
     mark(4);
 
     hipLaunchKernelGGL((k_reduce<C>), dim3(partial_stride, num_tasks), dim3(kReduceThreads), 0,
-                       stream, d_partials, partial_stride, d_bucket_sums, d_bucket_end, d_tasks);
+                       stream, d_partials, partial_stride, d_bucket_sums, d_heads, d_bucket_end,
+                       d_tasks);
     mark(5);
 
     hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
-                       out_stride, projective_out ? 1 : 0, d_partials, partial_stride, d_cols,
-                       d_tasks);
+                       out_stride, projective_out ? 1 : 0, d_partials, partial_stride, d_cols);
     mark(6);
     if (timing) ctx.timer.calls += 1;
   } else {
     // every column is empty: identities only
     hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
-                       out_stride, projective_out ? 1 : 0, nullptr, partial_stride, d_cols, d_tasks);
+                       out_stride, projective_out ? 1 : 0, nullptr, partial_stride, d_cols);
   }
-  g_kernel_launches += num_tasks > 0 ? 5 : 1;
+  g_kernel_launches += num_tasks > 0 ? 7 : 1;
   BZ_HIP_CHECK(hipGetLastError());
 }
 

@@ -1,19 +1,25 @@
 // gfx950 kernels of the variable-base MSM (Pippenger with signed windows, counting-sorted
-// buckets).  Stage by stage (reference counterparts in SURVEY.md section 2.3):
+// buckets, load-balanced segment accumulation).  Stage by stage (reference counterparts in
+// SURVEY.md section 2.3):
 //
 //   k_prepare_addends  caller generators (C-ABI layout) -> resident addend array
 //   k_recode           scalars -> signed radix-2^c digits, transposed to [task][row] int16
 //                      (reference: mtxb digit extraction, sxt/multiexp/base/digit_utility.cc:27-98,
 //                       and the scalar transpose sxt/multiexp/base/scalar_array.cc:34-104)
-//   k_bucket_sort      per task: LDS histogram -> LDS exclusive scan -> LDS-cursor scatter of row
-//                      indices, i.e. a counting sort by bucket (reference K1/K2:
-//                      bucket_method2/multiproduct_table_kernel.h:32-93, multiproduct_table.cc:74-82)
-//   k_accumulate       one lane per bucket: gather addends by sorted index, mixed-add
+//   k_bucket_hist      per (task, 64 Ki-row slice): LDS histogram of the digits -> global counts
+//   k_bucket_offsets   per (task, 512 buckets): exclusive scan over (bucket, slice) -> the start
+//                      offset of every slice's share of every bucket + bucket end offsets
+//   k_bucket_scatter   per (task, slice): LDS cursors, scatter of `row | sign << 31`
+//                      (together a counting sort by bucket; reference K1/K2:
+//                       bucket_method2/multiproduct_table_kernel.h:32-93, multiproduct_table.cc:74-82)
+//   k_accumulate       one lane per 32 consecutive *sorted entries* (not per bucket): gather
+//                      addends, mixed-add, flush at bucket boundaries; a bucket that straddles
+//                      lanes leaves "head" partials that k_reduce folds in
 //                      (reference K3 bucket_method2/sum.h:41-72, K5 bucket_method/
-//                       accumulation_kernel.h:37-75)
+//                       accumulation_kernel.h:37-75: one thread per bucket)
 //   k_reduce           per task: sum_b (b + 1) * bucket[b]  (reference K4 bucket_method2/reduce.h:50-78,
 //                      K8 + host combine_buckets bucket_method/combination.h:27-63)
-//   k_combine          per column: group sums, Horner over windows, canonical encoding
+//   k_combine          per column: Horner over windows, canonical encoding
 //                      (reference: host rsto::batch_compress / batch_to_element_affine,
 //                       sxt/cbindings/backend/cpu_backend.cc:117-152)
 //
@@ -50,8 +56,8 @@ __global__ void __launch_bounds__(256)
 // One lane per row.  Loads the little-endian scalar (1..32 bytes; two's complement when the column
 // is signed, in which case |x| is recoded and every digit is negated), produces W signed digits
 // D_w in [-2^(c-1), 2^(c-1)] with  x = sum_w D_w 2^(c w), and stores E = -D as int16 at
-// digits[task.entry_base + row_in_group].  (Storing -D keeps c = 16 inside int16: D in
-// [-32767, 32768].  Signed columns use c <= 15, enforced by the planner.)
+// digits[task.entry_base + row].  (Storing -D keeps c = 16 inside int16: D in [-32767, 32768].
+// Signed columns use c <= 15, enforced by the planner.)
 static __global__ void __launch_bounds__(256)
     k_recode(i16* __restrict__ digits, const column_desc* __restrict__ columns,
              const task_desc* __restrict__ tasks) {
@@ -61,139 +67,242 @@ static __global__ void __launch_bounds__(256)
   digit_recoder rec;
   rec.init(col.data + row * col.row_stride, col.bit_offset, col.bit_width, col.is_signed != 0,
            col.window_bits);
-  const u32 group = static_cast<u32>(row / col.rows_per_group);
-  const u32 r = static_cast<u32>(row - static_cast<u64>(group) * col.rows_per_group);
   for (u32 wi = 0; wi < col.num_windows; ++wi) {
     const int d = rec.next();
-    const task_desc& task = tasks[col.first_task + wi * col.num_groups + group];
-    digits[task.entry_base + r] = static_cast<i16>(-d);
+    digits[tasks[col.first_task + wi].entry_base + row] = static_cast<i16>(-d);
   }
 }
 
 //--------------------------------------------------------------------------------------------------
-// k_bucket_sort
+// counting sort by bucket: k_bucket_hist -> k_bucket_offsets -> k_bucket_scatter
 //--------------------------------------------------------------------------------------------------
-// One 1024-lane workgroup per task.  The task's 2^(c-1) bucket counters live in LDS (128 KiB at
-// c = 16): pass 1 histograms the digits with LDS atomics, an in-LDS exclusive scan turns counts
-// into cursors, pass 2 re-reads the digits (L2-resident) and scatters `row | sign << 31` through
-// the LDS cursors.  Output: sorted[entry_base + ...] grouped by bucket, bucket_end[bucket_base + b]
-// = end offset of bucket b (start = end of b - 1).
-static __global__ void __launch_bounds__(kSortThreads)
-    k_bucket_sort(u32* __restrict__ sorted, u32* __restrict__ bucket_end,
-                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  __shared__ u32 wave_sums[kSortThreads / 64];
-  const task_desc task = tasks[blockIdx.x];
-  const u32 nb = task.num_buckets;
-  const u32 tid = threadIdx.x;
-  for (u32 b = tid; b < nb; b += kSortThreads) lds[b] = 0;
-  __syncthreads();
-
-  const i16* dig = digits + task.entry_base;
-  const u32 rows = task.row_count;
-  // entry ranges are padded to multiples of 8 entries -> 16-byte vector loads are in bounds
+// The three kernels visit the digits of a (task, slice) in the same vectorised order.  `fn(r, e)`
+// is called for every non-zero stored digit e = -D of row r (relative to the slice).
+template <class F>
+__device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig, u32 rows, F&& fn) {
+  // slices start at multiples of kSliceRows and entry ranges are padded to multiples of 8
+  // entries, so 16-byte vector loads are aligned and in bounds
   const u32 nvec = (rows + 7) / 8;
   const uint4* dig4 = reinterpret_cast<const uint4*>(dig);
-  for (u32 v = tid; v < nvec; v += kSortThreads) {
+  for (u32 v = threadIdx.x; v < nvec; v += kSortThreads) {
     const uint4 pack = dig4[v];
     const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const u32 r = v * 8 + k;
       const int e = static_cast<i16>(words[k >> 1] >> (16 * (k & 1)));
-      if (r < rows && e != 0) {
-        const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
-        atomicAdd(&lds[mag - 1], 1u);
-      }
+      if (r < rows && e != 0) fn(r, e);
     }
   }
-  __syncthreads();
+}
 
-  // exclusive scan of nb counters by 1024 lanes, nb / 1024 consecutive counters per lane
-  const u32 per = (nb + kSortThreads - 1) / kSortThreads;
-  const u32 first = tid * per;
-  u32 local = 0;
-  for (u32 k = 0; k < per; ++k) {
-    const u32 b = first + k;
-    if (b < nb) local += lds[b];
+// counts[task.hist_base + slice * nb + b] = digits of the slice in bucket b;
+// chunk_totals[task.chunk_base + b / 512] += the slice's digits in that chunk of buckets
+static __global__ void __launch_bounds__(kSortThreads)
+    k_bucket_hist(u32* __restrict__ counts, u32* __restrict__ chunk_totals,
+                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const task_desc task = tasks[blockIdx.y];
+  const u32 slice = blockIdx.x;
+  if (slice >= task.num_slices) return;
+  const u32 nb = task.num_buckets;
+  const u32 tid = threadIdx.x;
+  for (u32 b = tid; b < nb; b += kSortThreads) lds[b] = 0;
+  __syncthreads();
+  const u64 row0 = static_cast<u64>(slice) * kSliceRows;
+  const u32 rows = static_cast<u32>(task.rows - row0 < kSliceRows ? task.rows - row0 : kSliceRows);
+  for_each_slice_digit(digits + task.entry_base + row0, rows, [&](u32, int e) {
+    const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
+    atomicAdd(&lds[mag - 1], 1u);
+  });
+  __syncthreads();
+  u32* out = counts + task.hist_base + static_cast<u64>(slice) * nb;
+  for (u32 b = tid; b < nb; b += kSortThreads) out[b] = lds[b];
+  // per-chunk totals: one wave per chunk, 8 counters per lane at the full chunk size
+  const u32 lane = tid & 63, wave = tid >> 6;
+  const u32 chunks = (nb + kOffsetChunkBuckets - 1) / kOffsetChunkBuckets;
+  for (u32 ch = wave; ch < chunks; ch += kSortThreads / 64) {
+    u32 sum = 0;
+    for (u32 k = lane; k < kOffsetChunkBuckets; k += 64) {
+      const u32 b = ch * kOffsetChunkBuckets + k;
+      if (b < nb) sum += lds[b];
+    }
+#pragma unroll
+    for (u32 off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if (lane == 0 && sum != 0) atomicAdd(&chunk_totals[task.chunk_base + ch], sum);
   }
-  // wave-level inclusive scan
+}
+
+// In place: counts[slice][b] becomes the offset (inside the task's sorted entry list) at which the
+// slice's digits of bucket b start; bucket_end[bucket_base + b] = end offset of bucket b.
+// Order of the sorted list: bucket-major, slices in order inside a bucket.
+static __global__ void __launch_bounds__(256)
+    k_bucket_offsets(u32* __restrict__ counts, u32* __restrict__ bucket_end,
+                     const u32* __restrict__ chunk_totals, const task_desc* __restrict__ tasks) {
+  __shared__ u32 wave_sums[4];
+  __shared__ u32 chunk_base_sh;
+  const task_desc task = tasks[blockIdx.y];
+  const u32 nb = task.num_buckets;
+  const u32 ch = blockIdx.x;
+  if (ch * kOffsetChunkBuckets >= nb) return;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    u32 s = 0;
+    for (u32 k = lane; k < ch; k += 64) s += chunk_totals[task.chunk_base + k];
+#pragma unroll
+    for (u32 off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) chunk_base_sh = s;
+  }
+  // two adjacent buckets per lane
+  const u32 b0 = ch * kOffsetChunkBuckets + 2 * tid;
+  u32* col = counts + task.hist_base + b0;
+  const bool in0 = b0 < nb, in1 = b0 + 1 < nb;
+  u32 t0 = 0, t1 = 0;
+  if (in1) {
+    for (u32 s = 0; s < task.num_slices; ++s) {
+      const uint2 v = *reinterpret_cast<const uint2*>(col + static_cast<u64>(s) * nb);
+      t0 += v.x;
+      t1 += v.y;
+    }
+  } else if (in0) {
+    for (u32 s = 0; s < task.num_slices; ++s) t0 += col[static_cast<u64>(s) * nb];
+  }
+  // exclusive scan of the 512 bucket totals in bucket order
+  const u32 local = t0 + t1;
   u32 incl = local;
-  const u32 lane = tid & 63;
 #pragma unroll
   for (u32 off = 1; off < 64; off <<= 1) {
     const u32 up = __shfl_up(incl, off, 64);
     if (lane >= off) incl += up;
   }
-  if (lane == 63) wave_sums[tid >> 6] = incl;
+  if (lane == 63) wave_sums[wave] = incl;
   __syncthreads();
-  if (tid < 64) {
-    const u32 nw = kSortThreads / 64;
-    u32 s = tid < nw ? wave_sums[tid] : 0;
-    u32 si = s;
-#pragma unroll
-    for (u32 off = 1; off < 64; off <<= 1) {
-      const u32 up = __shfl_up(si, off, 64);
-      if (tid >= off) si += up;
+  u32 base = chunk_base_sh;
+  for (u32 w = 0; w < wave; ++w) base += wave_sums[w];
+  u32 run0 = base + incl - local;
+  u32 run1 = run0 + t0;
+  if (in0) bucket_end[task.bucket_base + b0] = run0 + t0;
+  if (in1) bucket_end[task.bucket_base + b0 + 1] = run1 + t1;
+  if (in1) {
+    for (u32 s = 0; s < task.num_slices; ++s) {
+      uint2* p = reinterpret_cast<uint2*>(col + static_cast<u64>(s) * nb);
+      const uint2 v = *p;
+      *p = make_uint2(run0, run1);
+      run0 += v.x;
+      run1 += v.y;
     }
-    if (tid < nw) wave_sums[tid] = si - s; // exclusive
-  }
-  __syncthreads();
-  u32 run = wave_sums[tid >> 6] + incl - local;
-  for (u32 k = 0; k < per; ++k) {
-    const u32 b = first + k;
-    if (b < nb) {
-      const u32 cnt = lds[b];
-      lds[b] = run; // cursor = start offset
-      run += cnt;
-      bucket_end[task.bucket_base + b] = run;
+  } else if (in0) {
+    for (u32 s = 0; s < task.num_slices; ++s) {
+      u32* p = col + static_cast<u64>(s) * nb;
+      const u32 v = *p;
+      *p = run0;
+      run0 += v;
     }
   }
-  __syncthreads();
+}
 
+// sorted[task.entry_base + pos] = row | (digit negative) << 31, grouped by bucket;
+// segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment
+static __global__ void __launch_bounds__(kSortThreads)
+    k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                     const u32* __restrict__ offsets, const i16* __restrict__ digits,
+                     const task_desc* __restrict__ tasks) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const task_desc task = tasks[blockIdx.y];
+  const u32 slice = blockIdx.x;
+  if (slice >= task.num_slices) return;
+  const u32 nb = task.num_buckets;
+  const u32 tid = threadIdx.x;
+  const u32* in = offsets + task.hist_base + static_cast<u64>(slice) * nb;
+  for (u32 b = tid; b < nb; b += kSortThreads) lds[b] = in[b];
+  __syncthreads();
+  const u64 row0 = static_cast<u64>(slice) * kSliceRows;
+  const u32 rows = static_cast<u32>(task.rows - row0 < kSliceRows ? task.rows - row0 : kSliceRows);
   u32* out = sorted + task.entry_base;
-  for (u32 v = tid; v < nvec; v += kSortThreads) {
-    const uint4 pack = dig4[v];
-    const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u32 r = v * 8 + k;
-      const int e = static_cast<i16>(words[k >> 1] >> (16 * (k & 1)));
-      if (r < rows && e != 0) {
-        // E = -D: positive E means the digit is negative -> subtract the generator
-        const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
-        const u32 pos = atomicAdd(&lds[mag - 1], 1u);
-        out[pos] = r | (e > 0 ? 0x80000000u : 0u);
-      }
-    }
-  }
+  u32* seg = segment_bucket + task.segment_base;
+  for_each_slice_digit(digits + task.entry_base + row0, rows, [&](u32 r, int e) {
+    // E = -D: positive E means the digit is negative -> subtract the generator
+    const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
+    const u32 pos = atomicAdd(&lds[mag - 1], 1u);
+    out[pos] = (static_cast<u32>(row0) + r) | (e > 0 ? 0x80000000u : 0u);
+    if (pos % kSegmentEntries == 0) seg[pos / kSegmentEntries] = mag - 1;
+  });
 }
 
 //--------------------------------------------------------------------------------------------------
 // k_accumulate
 //--------------------------------------------------------------------------------------------------
-// One lane per bucket: walk the bucket's slice of the sorted index array, gather each addend from
-// the resident generator array and mixed-add it into a register-resident accumulator.
+// One lane per segment of kSegmentEntries consecutive sorted entries.  The lane walks its entries,
+// gathers each addend from the resident generator array and adds it into a register-resident
+// accumulator; at a bucket boundary the accumulator is flushed.  The lane in whose segment a
+// bucket *starts* owns bucket_sums[bucket]; a lane that begins in the middle of a bucket writes
+// that first partial to heads[segment] instead (k_reduce adds the heads of a bucket to its sum).
+// Every lane therefore does at most kSegmentEntries additions, whatever the digit distribution.
 template <class C>
-__global__ void __launch_bounds__(kAccumulateThreads)
-    k_accumulate(typename C::point* __restrict__ bucket_sums, const u32* __restrict__ bucket_end,
+__global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_simd)
+    k_accumulate(typename C::point* __restrict__ bucket_sums, typename C::point* __restrict__ heads,
+                 const u32* __restrict__ bucket_end, const u32* __restrict__ segment_bucket,
                  const u32* __restrict__ sorted, const typename C::addend* __restrict__ addends,
                  const task_desc* __restrict__ tasks) {
   const task_desc task = tasks[blockIdx.y];
-  const u32 b = blockIdx.x * kAccumulateThreads + threadIdx.x;
-  if (b >= task.num_buckets) return;
   const u32* ends = bucket_end + task.bucket_base;
-  const u32 begin = b == 0 ? 0 : ends[b - 1];
-  const u32 end = ends[b];
+  const u32 total = ends[task.num_buckets - 1];
+  const u32 seg = blockIdx.x * kAccumulateThreads + threadIdx.x;
+  const u32 lo = seg * kSegmentEntries;
+  if (lo >= total) return;
+  const u32 hi = lo + kSegmentEntries < total ? lo + kSegmentEntries : total;
+  u32 b = segment_bucket[task.segment_base + seg];
+  u32 b_end = ends[b];
+  const u32 b_start = b == 0 ? 0 : ends[b - 1];
+  bool owned = b_start == lo;
   const u32* idx = sorted + task.entry_base;
-  const typename C::addend* gens = addends + task.row_begin;
+  typename C::point* sums = bucket_sums + task.bucket_base;
   typename C::point acc = C::identity();
-  for (u32 i = begin; i < end; ++i) {
-    const u32 e = idx[i];
-    const typename C::addend q = gens[e & 0x7fffffffu];
+  // software pipeline, one entry ahead: the gather of the next addend (two dependent loads:
+  // index, then 144..192 bytes from a random row of the generator table) is in flight while the
+  // current addition (~1500 VALU instructions) executes, so a wave hides its own memory latency
+  // instead of relying on the 3-4 co-resident waves all being out of phase.
+  u32 e_next = idx[lo];
+  u32 e_after = lo + 1 < hi ? idx[lo + 1] : 0;
+  typename C::addend q_next = addends[e_next & 0x7fffffffu];
+  for (u32 i = lo; i < hi; ++i) {
+    if (i == b_end) {
+      if (owned) {
+        sums[b] = acc;
+      } else {
+        heads[task.segment_base + seg] = acc;
+      }
+      do {
+        ++b;
+        b_end = ends[b];
+      } while (b_end == i);
+      owned = true;
+      acc = C::identity();
+    }
+    const u32 e = e_next;
+    const typename C::addend q = q_next;
+    e_next = e_after; // index loaded one iteration ago: the addend gather below does not wait on it
+    if (i + 1 < hi) q_next = addends[e_next & 0x7fffffffu];
+    if (i + 2 < hi) e_after = idx[i + 2];
     C::accumulate(acc, q, (e >> 31) != 0);
   }
-  bucket_sums[task.bucket_base + b] = acc;
+  if (owned) {
+    sums[b] = acc;
+  } else {
+    heads[task.segment_base + seg] = acc;
+  }
+}
+
+// complete sum of bucket b of a task: the owner's partial plus the heads of the following
+// segments the bucket extends into
+template <class C>
+__device__ __forceinline__ typename C::point
+load_bucket(const typename C::point* __restrict__ sums, const typename C::point* __restrict__ heads,
+            u32 begin, u32 end, u32 b) {
+  typename C::point v = sums[b];
+  const u32 first = begin / kSegmentEntries, last = (end - 1) / kSegmentEntries;
+  for (u32 s = first + 1; s <= last; ++s) v = C::add(v, heads[s]);
+  return v;
 }
 
 //--------------------------------------------------------------------------------------------------
@@ -206,7 +315,8 @@ __global__ void __launch_bounds__(kAccumulateThreads)
 template <class C>
 __global__ void __launch_bounds__(kReduceThreads)
     k_reduce(typename C::point* __restrict__ partials, u32 partial_stride,
-             const typename C::point* __restrict__ bucket_sums, const u32* __restrict__ bucket_end,
+             const typename C::point* __restrict__ bucket_sums,
+             const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
              const task_desc* __restrict__ tasks) {
   using point = typename C::point;
   __shared__ point tree[kReduceThreads];
@@ -230,11 +340,15 @@ __global__ void __launch_bounds__(kReduceThreads)
     const u32 hi = ends[seg_last - 1];
     if (hi != lo) {
       const point* bs = bucket_sums + task.bucket_base;
+      const point* hd = heads + task.segment_base;
       point s = C::identity();
       point r = C::identity();
+      u32 end = hi;
       for (u32 b = seg_last; b-- > seg_first;) {
-        s = C::add(s, bs[b]);
+        const u32 begin = b == 0 ? 0 : ends[b - 1];
+        if (begin != end) s = C::add(s, load_bucket<C>(bs, hd, begin, end, b));
         r = C::add(r, s);
+        end = begin;
       }
       // r = sum (b - seg_first + 1) B_b ; add seg_first * s
       contrib = r;
@@ -264,15 +378,16 @@ __global__ void __launch_bounds__(kReduceThreads)
 //--------------------------------------------------------------------------------------------------
 // k_combine
 //--------------------------------------------------------------------------------------------------
-// One workgroup per column: fold the per-(window, group, block) partials into one sum per window
-// (all windows concurrently, a power-of-two team of lanes per window), then lane 0 runs the Horner
-// recurrence  acc = 2^c acc + window[w]  from the top window down and writes the canonical
-// encoding (or the raw projective point when `projective_out`).
+// One workgroup per column: fold the per-(window, block) partials into one sum per window (all
+// windows concurrently, a power-of-two team of lanes per window), then the Horner recurrence
+// acc = 2^c acc + window[w]  from the top window down -- on one lane, or on one wavefront when the
+// curve has a lane-cooperative form of the chain (C::wave_horner) -- and the canonical encoding
+// (or the raw projective point when `projective_out`).
 template <class C>
 __global__ void __launch_bounds__(kCombineThreads)
     k_combine(u8* __restrict__ out, u32 out_stride, int projective_out,
               const typename C::point* __restrict__ partials, u32 partial_stride,
-              const column_desc* __restrict__ columns, const task_desc* __restrict__ tasks) {
+              const column_desc* __restrict__ columns) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
   const column_desc col = columns[blockIdx.x];
@@ -296,14 +411,10 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 lane = tid % team;
   const u32 nb = 1u << (col.window_bits - 1);
   const u32 blocks = (nb + kReduceBlockBuckets - 1) / kReduceBlockBuckets;
-  const u32 P = col.num_groups * blocks;
   point sum = C::identity();
   if (w < W) {
-    for (u32 e = lane; e < P; e += team) {
-      const u32 g = e / blocks, blk = e % blocks;
-      const u32 t = col.first_task + w * col.num_groups + g;
-      sum = C::add(sum, partials[static_cast<u64>(t) * partial_stride + blk]);
-    }
+    const point* p = partials + static_cast<u64>(col.first_task + w) * partial_stride;
+    for (u32 blk = lane; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
   }
   tree[tid] = sum;
   __syncthreads();
@@ -311,16 +422,29 @@ __global__ void __launch_bounds__(kCombineThreads)
     if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
     __syncthreads();
   }
-  if (tid == 0) {
-    point acc = tree[(W - 1) * team];
-    for (u32 wi = W - 1; wi-- > 0;) {
-      acc = C::dbl_n(acc, static_cast<int>(col.window_bits));
-      acc = C::add(acc, tree[wi * team]);
+  if constexpr (C::has_wave_horner) {
+    if (tid < 64) {
+      const point acc = C::wave_horner(tree, team, W, col.window_bits);
+      if (tid == 0) {
+        if (projective_out) {
+          C::store_projective(dst, acc);
+        } else {
+          C::encode(dst, acc);
+        }
+      }
     }
-    if (projective_out) {
-      C::store_projective(dst, acc);
-    } else {
-      C::encode(dst, acc);
+  } else {
+    if (tid == 0) {
+      point acc = tree[(W - 1) * team];
+      for (u32 wi = W - 1; wi-- > 0;) {
+        acc = C::dbl_n(acc, static_cast<int>(col.window_bits));
+        acc = C::add(acc, tree[wi * team]);
+      }
+      if (projective_out) {
+        C::store_projective(dst, acc);
+      } else {
+        C::encode(dst, acc);
+      }
     }
   }
 }

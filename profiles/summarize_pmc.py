@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise tools/prof/run_pmc.sh output (rocprofv3 csv) as markdown: per-kernel durations from
+the --kernel-trace --stats pass and per-kernel averages of the PMC counters of the other passes.
+
+    python profiles/summarize_pmc.py gpurun_out/prof_<tag> > profiles/<round>_<tag>.md
+"""
+import collections
+import csv
+import os
+import re
+import sys
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    m = re.match(r"(?:bz::)?(?:\(anonymous namespace\)::)?([A-Za-z_0-9:]+)(<[^>]*>)?", name)
+    s = (m.group(1) + (m.group(2) or "")) if m else name
+    return s[:60]
+
+
+def main():
+    root = sys.argv[1]
+    print(f"# rocprofv3 summary of `{root}`\n")
+    stats = os.path.join(root, "trace", "r_kernel_stats.csv")
+    if os.path.exists(stats):
+        print("## --kernel-trace --stats\n\n| kernel | calls | avg_us | total_us | % |\n|---|---|---|---|---|")
+        for r in csv.DictReader(open(stats)):
+            print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | "
+                  f"{float(r['TotalDurationNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for sub in sorted(os.listdir(root)):
+        f = os.path.join(root, sub, "r_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        per_dispatch = collections.defaultdict(float)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            per_dispatch[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+            meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"],
+                       r["LDS_Block_Size"])
+        for (k, _, c), v in per_dispatch.items():
+            counters[k][c].append(v)
+    if counters:
+        names = sorted({c for k in counters for c in counters[k]})
+        print("\n## PMC counters (average per dispatch)\n")
+        print("| kernel | grid | wg | vgpr | sgpr | lds | " + " | ".join(names) + " |")
+        print("|---|---|---|---|---|---|" + "---|" * len(names))
+        for k in sorted(counters):
+            if not k.startswith("k_"):
+                continue
+            vals = [f"{sum(counters[k][c]) / len(counters[k][c]):.4g}" if c in counters[k] else ""
+                    for c in names]
+            print(f"| {k} | " + " | ".join(meta[k]) + " | " + " | ".join(vals) + " |")
+        print("\nFETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts wide "
+              "streaming reads at half their bytes (MI355X_MICROARCH.md, HBM section).")
+
+
+if __name__ == "__main__":
+    main()

@@ -155,7 +155,45 @@ def recode(row_bytes, bit_offset, bit_width, is_signed, window_bits, num_windows
 def plan(ns, bit_widths, signed, max_window_bits=16):
     k = len(ns)
     per = np.zeros((k, 4), np.uint32)
-    totals = np.zeros(5, np.uint64)
+    totals = np.zeros(6, np.uint64)
     lib().bz_plan(_p(per), _p(totals), _p(_c(ns)), _p(_c(bit_widths, np.uint32)),
                   _p(_c(signed, np.int32)), ctypes.c_uint32(k), ctypes.c_uint32(max_window_bits))
     return per, totals
+
+
+def f29_from_fe51(f):
+    out = np.zeros(9, np.uint32)
+    lib().bz_f29_from_fe51(_p(out), _p(_c(f)))
+    return out
+
+
+def f29_to_int(f):
+    w = np.zeros(4, np.uint64)
+    lib().bz_f29_to_words(_p(w), _p(_c(f, np.uint32)))
+    return int.from_bytes(w.tobytes(), "little")
+
+
+def f29(op, *args):
+    out = np.zeros(9, np.uint32)
+    getattr(lib(), f"bz_f29_{op}")(_p(out), *[_p(_c(a, np.uint32)) for a in args])
+    return out
+
+
+def ed29_add(a, b, negate=False):
+    out = np.zeros(20, np.uint64)
+    lib().bz_ed29_add(_p(out), _p(_c(a)), _p(_c(b)), ctypes.c_int(1 if negate else 0))
+    return out
+
+
+def ed29_dbl_n(a, k):
+    out = np.zeros(20, np.uint64)
+    lib().bz_ed29_dbl_n(_p(out), _p(_c(a)), ctypes.c_int(k))
+    return out
+
+
+def ed29_chain(points, negate):
+    out = np.zeros(20, np.uint64)
+    pts = _c(points)
+    neg = _c(negate, np.int32)
+    lib().bz_ed29_chain(_p(out), _p(pts), _p(neg), ctypes.c_int(pts.shape[0]))
+    return out

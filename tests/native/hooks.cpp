@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "blitzar_amd/csrc/curve/ed25519.h"
+#include "blitzar_amd/csrc/curve/ed29.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
 #include "blitzar_amd/csrc/msm/plan.h"
 #include "blitzar_amd/csrc/msm/recode.h"
@@ -152,8 +153,8 @@ int bz_recode(int* digits, const u8* row, u32 bit_offset, u32 bit_width, int is_
   return static_cast<int>(num_windows);
 }
 
-// planner (msm/plan.h): per column {window_bits, num_windows, num_groups, rows_per_group};
-// totals {tasks, total_buckets, total_entries, max_task_rows}
+// planner (msm/plan.h): per column {window_bits, num_windows, slices, first_task};
+// totals {tasks, total_buckets, total_entries, total_segments, rows covered, total_hist}
 void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, const int* is_signed,
              u32 num_columns, u32 max_window_bits) {
   std::vector<host_column> cols(num_columns);
@@ -164,18 +165,90 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
   tune.max_window_bits = max_window_bits;
   msm_plan plan = make_msm_plan(cols, tune);
   for (u32 i = 0; i < num_columns; ++i) {
-    per_column[4 * i + 0] = plan.columns[i].window_bits;
-    per_column[4 * i + 1] = plan.columns[i].num_windows;
-    per_column[4 * i + 2] = plan.columns[i].num_groups;
-    per_column[4 * i + 3] = plan.columns[i].rows_per_group;
+    const column_desc& c = plan.columns[i];
+    per_column[4 * i + 0] = c.window_bits;
+    per_column[4 * i + 1] = c.num_windows;
+    per_column[4 * i + 2] = c.num_windows == 0 ? 0 : plan.tasks[c.first_task].num_slices;
+    per_column[4 * i + 3] = c.first_task;
   }
   totals[0] = plan.tasks.size();
   totals[1] = plan.total_buckets;
   totals[2] = plan.total_entries;
-  totals[3] = plan.max_task_rows;
-  // every row of every column is covered exactly once per window
+  totals[3] = plan.total_segments;
   u64 covered = 0;
-  for (const auto& t : plan.tasks) covered += t.row_count;
+  for (const auto& t : plan.tasks) covered += t.rows;
   totals[4] = covered;
+  totals[5] = plan.total_hist;
+}
+
+// 9 x 29-bit field of the gfx950 kernels (field/f29.h); limbs in/out are raw u32[9]
+void bz_f29_from_fe51(u32* h, const u64* f) {
+  fe51 a;
+  std::memcpy(&a, f, 40);
+  fe29 r = f29::from_fe51(a);
+  std::memcpy(h, &r, 36);
+}
+void bz_f29_to_words(u64* w, const u32* f) {
+  fe29 a;
+  std::memcpy(&a, f, 36);
+  f29::to_words(w, a);
+}
+void bz_f29_mul(u32* h, const u32* f, const u32* g) {
+  fe29 a, b;
+  std::memcpy(&a, f, 36);
+  std::memcpy(&b, g, 36);
+  fe29 r = f29::mul(a, b);
+  std::memcpy(h, &r, 36);
+}
+void bz_f29_sq(u32* h, const u32* f) {
+  fe29 a;
+  std::memcpy(&a, f, 36);
+  fe29 r = f29::sq(a);
+  std::memcpy(h, &r, 36);
+}
+void bz_f29_sub(u32* h, const u32* f, const u32* g) {
+  fe29 a, b;
+  std::memcpy(&a, f, 36);
+  std::memcpy(&b, g, 36);
+  fe29 r = f29::sub(a, b);
+  std::memcpy(h, &r, 36);
+}
+void bz_f29_weak_reduce(u32* h, const u32* f) {
+  fe29 a;
+  std::memcpy(&a, f, 36);
+  fe29 r = f29::weak_reduce(a);
+  std::memcpy(h, &r, 36);
+}
+void bz_f29_invert(u32* h, const u32* f) {
+  fe29 a;
+  std::memcpy(&a, f, 36);
+  fe29 r = f29::invert(a);
+  std::memcpy(h, &r, 36);
+}
+// out = a + b (or a - b) computed on the 29-bit representation, returned as fe51 element_p3
+void bz_ed29_add(u64* out, const u64* a, const u64* b, int negate) {
+  ed_point p, q;
+  std::memcpy(&p, a, 160);
+  std::memcpy(&q, b, 160);
+  ed29_point r = ed29::add_cached(ed29::from_ed(p), ed29::cached_from_ed(q), negate != 0);
+  ed_point e = ed29::to_ed(r);
+  std::memcpy(out, &e, 160);
+}
+void bz_ed29_dbl_n(u64* out, const u64* a, int k) {
+  ed_point p;
+  std::memcpy(&p, a, 160);
+  ed_point e = ed29::to_ed(ed29::dbl_n(ed29::from_ed(p), k));
+  std::memcpy(out, &e, 160);
+}
+// long chain: acc = sum_i (+-) q_i, stressing the limb bounds of repeated accumulation
+void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
+  ed29_point acc = ed29::identity();
+  for (int i = 0; i < n; ++i) {
+    ed_point q;
+    std::memcpy(&q, points + 20 * i, 160);
+    acc = ed29::add_cached(acc, ed29::cached_from_ed(q), negate[i] != 0);
+  }
+  ed_point e = ed29::to_ed(acc);
+  std::memcpy(out, &e, 160);
 }
 }

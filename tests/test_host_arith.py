@@ -150,20 +150,106 @@ def test_signed_digit_recoding_reconstructs_the_scalar():
 
 
 def test_planner_invariants():
-    ns = [0, 1, 97, 5000, 1 << 16, 1 << 20, (1 << 20) + 3, 1 << 22]
-    widths = [256, 8, 32, 256, 64, 256, 1, 256]
+    ns = [0, 1, 97, 5000, 1 << 16, (1 << 16) + 1, 1 << 20, (1 << 20) + 3, 1 << 22]
+    widths = [256, 8, 32, 256, 64, 16, 256, 1, 256]
     per, totals = hooks.plan(ns, widths, [0] * len(ns))
-    assert per[0].tolist() == [1, 0, 0, 0]  # empty column: no tasks
-    covered = 0
-    for n, bw, (c, W, G, rpg) in zip(ns, widths, per.tolist()):
+    assert per[0].tolist()[:3] == [1, 0, 0]  # empty column: no tasks
+    covered = tasks = segs = hist = 0
+    for n, bw, (c, W, slices, first) in zip(ns, widths, per.tolist()):
         if n == 0:
             continue
+        assert first == tasks
         assert 2 <= c <= 16 and W * c >= bw + 1          # top digit never carries out
-        assert G * rpg >= n and (G - 1) * rpg < n        # groups tile the rows
-        assert rpg <= 1 << 20                             # 31-bit row index + sign per entry
+        assert slices == (n + 65535) // 65536            # one sort workgroup per 64 Ki rows
         covered += W * n
-    assert int(totals[4]) == covered
-    assert int(totals[0]) == sum(W * G for (_, W, G, _) in per.tolist())
+        tasks += W
+        segs += W * ((n + 31) // 32)
+        hist += W * slices * (1 << (c - 1))
+    assert int(totals[0]) == tasks and int(totals[4]) == covered
+    assert int(totals[3]) == segs and int(totals[5]) == hist
     # signed columns are planned with c <= 15 by the engine (digits must fit int16 negated)
     per, _ = hooks.plan([1 << 20], [128], [1], max_window_bits=15)
     assert per[0][0] <= 15
+
+
+#--------------------------------------------------------------------------------------------------
+# the 9 x 29-bit field / curve code the gfx950 kernels compute in (field/f29.h, curve/ed29.h)
+#--------------------------------------------------------------------------------------------------
+P25519 = (1 << 255) - 19
+
+
+def f29_value(limbs):
+    return sum(int(v) << (29 * i) for i, v in enumerate(limbs)) % P25519
+
+
+def f29_loose(rng, bound):
+    """limbs up to bound * 2^29 (the B of field/f29.h's contract), with saturated corner cases"""
+    hi = int(bound * (1 << 29))
+    v = rng.integers(0, hi, 9, dtype=np.uint64).astype(np.uint32)
+    k = int(rng.integers(0, 4))
+    if k == 0:
+        v[:] = hi - 1
+    elif k == 1:
+        v[int(rng.integers(0, 9))] = hi - 1
+    return v
+
+
+def test_f29_matches_integers_at_the_contract_bounds():
+    rng = np.random.default_rng(29)
+    for _ in range(300):
+        bf = float(rng.choice([1.0, 2.0, 3.0]))
+        bg = float(rng.choice([1.0, 2.0])) if bf > 2 else float(rng.choice([1.0, 2.0, 3.0]))
+        f, g = f29_loose(rng, bf + 0.001), f29_loose(rng, bg + 0.001)
+        h = hooks.f29("mul", f, g)
+        assert f29_value(h) == f29_value(f) * f29_value(g) % P25519
+        assert max(int(x) for x in h) < (1 << 29) + (1 << 18)
+        assert hooks.f29_to_int(h) == f29_value(h)
+        f2 = f29_loose(rng, 2.4)
+        s = hooks.f29("sq", f2)
+        assert f29_value(s) == f29_value(f2) ** 2 % P25519
+        assert max(int(x) for x in s) < (1 << 29) + (1 << 18)
+        # sub: B(g) < 1.99, any f up to B 5
+        f5, g2 = f29_loose(rng, 5.0), f29_loose(rng, 1.98)
+        d = hooks.f29("sub", f5, g2)
+        assert f29_value(d) == (f29_value(f5) - f29_value(g2)) % P25519
+        w = hooks.f29("weak_reduce", f29_loose(rng, 7.0))
+        assert max(int(x) for x in w) <= (1 << 29)
+    z = f29_loose(rng, 1.0)
+    assert f29_value(hooks.f29("invert", z)) * f29_value(z) % P25519 == 1
+
+
+def test_f29_fe51_conversions():
+    rng = np.random.default_rng(30)
+    edge = [np.zeros(5, np.uint64), np.full(5, MASK51, np.uint64),
+            np.array([MASK51 - 18, MASK51, MASK51, MASK51, MASK51], np.uint64),
+            np.array([MASK51 - 19, MASK51, MASK51, MASK51, MASK51], np.uint64),
+            np.full(5, (1 << 54) - 1, np.uint64)]
+    cases = edge + [rand_f51(rng, i % 2 == 0) for i in range(200)]
+    for f in cases:
+        want = sum(int(v) << (51 * i) for i, v in enumerate(f)) % P25519
+        h = hooks.f29_from_fe51(f)
+        assert f29_value(h) == want
+        assert hooks.f29_to_int(h) == want      # canonical: exactly the residue in [0, p)
+
+
+def test_ed29_group_law_matches_reference(oracle):
+    g = oracle.ristretto_generators(40, 11)
+    canon = oracle.ristretto_compress
+    for i in range(0, 12, 2):
+        a, b = g[i], g[i + 1]
+        assert np.array_equal(canon(hooks.ed29_add(a, b)), canon(oracle.add_projective(0, a, b)))
+        assert np.array_equal(canon(hooks.ed29_add(a, b, True)), canon(hooks.ed_sub(a, b)))
+        assert np.array_equal(canon(hooks.ed29_add(a, a)), canon(oracle.double_projective(0, a)))
+        assert np.array_equal(canon(hooks.ed29_add(a, a, True)), np.zeros(32, np.uint8))
+        d = a
+        for k in range(1, 18):
+            d = oracle.double_projective(0, d)
+            if k in (1, 2, 16, 17):
+                assert np.array_equal(canon(hooks.ed29_dbl_n(a, k)), canon(d))
+    # a long signed accumulation chain (what one bucket lane does), including the identity start
+    rng = np.random.default_rng(31)
+    signs = rng.integers(0, 2, 40)
+    acc = oracle.one_commit(0)
+    for q, s in zip(g, signs):
+        acc = hooks.ed_sub(acc, q) if s else oracle.add_projective(0, acc, q)
+    assert np.array_equal(canon(hooks.ed29_chain(g, signs)), canon(acc))
