@@ -156,7 +156,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64 limbs (radix-2^51 GF(2^255-19))",
+            "dtype": "u32 limbs (9 x 29-bit GF(2^255-19), v_mad_u64_u32 products)",
             "data": "synthetic: uniform random 252-bit scalars, built-in ristretto generators",
             "config": {"workload": name if args.log2n is None else f"curve25519_msm_n2^{log2n}_252bit",
                        "columns_per_gpu": 1, "rows": n, "parallelism": f"columns x{world}"},
@@ -169,9 +169,11 @@ def main():
             alg_bytes = n * (nbytes + gen_bytes)
             dur_s = per_call["accumulate"] * 1e-3
             achieved = alg_bytes / dur_s / 1e9
+            # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command
+            # (tools/prof/run_pmc.sh -> profiles/roofline_traffic.json); null until collected
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.log2n is None:
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("k_accumulate_bytes_per_launch")
             result["roofline"] = {

@@ -549,6 +549,14 @@ uint64_t bzamd_stage_timing_collect(double* out_ms) {
   return msm_context_timing_collect(st.context_for_current_device(), out_ms);
 }
 
+void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
+                      uint64_t max_workspace_bytes) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "tuning applies to the GPU backend");
+  msm_context_set_tuning(st.context_for_current_device(), max_window_bits, max_tasks_per_batch,
+                         max_workspace_bytes);
+}
+
 void bzamd_reset_for_testing(void) {
   if (g_state == nullptr) return;
   delete g_state;

@@ -20,6 +20,18 @@ const curve_vtable* curve_vtable_for(unsigned curve_id) {
 
 msm_context* msm_context_new() { return new msm_context(); }
 void msm_context_free(msm_context* ctx) { delete ctx; }
+void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
+                            size_t max_workspace_bytes) {
+  if (max_window_bits != 0) {
+    BZ_RELEASE_ASSERT(max_window_bits >= 2 && max_window_bits <= 16, "window width cap must be 2..16");
+    ctx->tuning.max_window_bits = max_window_bits;
+  }
+  if (max_tasks_per_batch != 0) {
+    BZ_RELEASE_ASSERT(max_tasks_per_batch <= 65535, "tasks per batch are a launch-grid dimension");
+    ctx->tuning.max_tasks_per_batch = max_tasks_per_batch;
+  }
+  if (max_workspace_bytes != 0) ctx->tuning.max_workspace_bytes = max_workspace_bytes;
+}
 void msm_context_timing_begin(msm_context* ctx, size_t max_calls) { ctx->timer.begin(max_calls); }
 size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]) {
   return ctx->timer.collect(out_ms);

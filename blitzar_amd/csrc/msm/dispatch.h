@@ -53,6 +53,10 @@ const curve_vtable* curve_vtable_for(unsigned curve_id);
 
 msm_context* msm_context_new();
 void msm_context_free(msm_context* ctx);
+// engine knobs (0 keeps the current value): window width cap (2..16), tasks and workspace bytes
+// per batch of columns
+void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
+                            size_t max_workspace_bytes);
 // per-stage HIP-event timing of the next `max_calls` MSM calls on this context
 void msm_context_timing_begin(msm_context* ctx, size_t max_calls);
 // accumulated ms per stage {prepare, recode, sort, accumulate, reduce, combine}; returns #calls

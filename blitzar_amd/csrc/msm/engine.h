@@ -66,15 +66,6 @@ template <class C> struct msm_workspace_sizes {
   size_t total = 0;
 };
 
-// Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.
-inline msm_plan plan_for_columns(const std::vector<host_column>& cols, const msm_tuning& tune) {
-  bool any_signed = false;
-  for (const auto& c : cols) any_signed = any_signed || c.is_signed;
-  msm_tuning t = tune;
-  if (any_signed && t.max_window_bits > 15) t.max_window_bits = 15;
-  return make_msm_plan(cols, t);
-}
-
 // one-time kernel attributes: the sort kernels need up to 128 KiB of dynamic LDS
 static void configure_sort_kernels() {
   static bool done = false;
@@ -86,26 +77,16 @@ static void configure_sort_kernels() {
   done = true;
 }
 
-// Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
-// (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
+// device workspace of one batch of columns (everything carved from the arena)
 template <class C>
-void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
-                 const std::vector<host_column>& cols, const typename C::addend* d_addends,
-                 const void* d_api_generators, hipStream_t stream) {
+size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial_stride) {
   using point = typename C::point;
   using addend = typename C::addend;
-  if (cols.empty()) return;
-  configure_sort_kernels();
-  const msm_plan plan = plan_for_columns(cols, ctx.tuning);
-  const u32 num_tasks = static_cast<u32>(plan.tasks.size());
-  const u32 num_cols = static_cast<u32>(plan.columns.size());
-  const u32 partial_stride =
-      plan.max_task_buckets == 0 ? 1 : ceil_div_u32(plan.max_task_buckets, kReduceBlockBuckets);
-
+  const size_t num_tasks = plan.tasks.size(), num_cols = plan.columns.size();
   size_t need = 0;
   need += device_arena::padded(sizeof(column_desc) * num_cols);
   need += device_arena::padded(sizeof(task_desc) * (num_tasks + 1));
-  if (d_addends == nullptr) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
+  if (needs_addends) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
   need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
   need += device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
   need += device_arena::padded(sizeof(u32) * (plan.total_hist + 2));
@@ -114,8 +95,88 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   need += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
-  need += device_arena::padded(sizeof(point) * (static_cast<size_t>(num_tasks) * partial_stride + 1));
+  need += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
+  return need;
+}
+
+inline u32 partial_stride_of(const msm_plan& plan) {
+  return plan.max_task_buckets == 0 ? 1 : ceil_div_u32(plan.max_task_buckets, kReduceBlockBuckets);
+}
+
+template <class C>
+void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                       const msm_plan& plan, const typename C::addend* d_addends,
+                       const void* d_api_generators, hipStream_t stream);
+
+// Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
+// (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
+// Columns are processed in batches bounded by the launch grid (tasks per batch) and by
+// `msm_tuning::max_workspace_bytes`; batches reuse the same arena back to back on the stream.
+template <class C>
+void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                 const std::vector<host_column>& cols, const typename C::addend* d_addends,
+                 const void* d_api_generators, hipStream_t stream) {
+  if (cols.empty()) return;
+  configure_sort_kernels();
+  msm_tuning tune = ctx.tuning;
+  bool any_signed = false;
+  for (const auto& c : cols) any_signed = any_signed || c.is_signed;
+  // Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.
+  if (any_signed && tune.max_window_bits > 15) tune.max_window_bits = 15;
+
+  std::vector<msm_plan> batches;
+  std::vector<size_t> first_column;
+  size_t need = 0;
+  for (size_t begin = 0; begin < cols.size();) {
+    size_t end = begin;
+    msm_plan plan;
+    // grow the batch column by column (re-planning a prefix is cheap: a few fields per task)
+    while (end < cols.size()) {
+      std::vector<host_column> trial(cols.begin() + begin, cols.begin() + end + 1);
+      msm_plan p = make_msm_plan(trial, tune);
+      const size_t bytes = msm_workspace_bytes<C>(p, d_addends == nullptr, partial_stride_of(p));
+      if (end > begin && (p.tasks.size() > tune.max_tasks_per_batch || bytes > tune.max_workspace_bytes)) {
+        break;
+      }
+      plan = std::move(p);
+      ++end;
+      // jump ahead in large uniform jobs: avoid quadratic re-planning
+      if (end - begin >= 8) {
+        const size_t step = end - begin;
+        while (end + step <= cols.size()) {
+          std::vector<host_column> t2(cols.begin() + begin, cols.begin() + end + step);
+          msm_plan p2 = make_msm_plan(t2, tune);
+          const size_t b2 = msm_workspace_bytes<C>(p2, d_addends == nullptr, partial_stride_of(p2));
+          if (p2.tasks.size() > tune.max_tasks_per_batch || b2 > tune.max_workspace_bytes) break;
+          plan = std::move(p2);
+          end += step;
+        }
+      }
+    }
+    const size_t bytes = msm_workspace_bytes<C>(plan, d_addends == nullptr, partial_stride_of(plan));
+    if (bytes > need) need = bytes;
+    first_column.push_back(begin);
+    batches.push_back(std::move(plan));
+    begin = end;
+  }
+  // one allocation sized for the largest batch: later resets never reallocate (no mid-call sync)
   ctx.arena.reset(need, stream);
+  for (size_t k = 0; k < batches.size(); ++k) {
+    ctx.arena.reset(need, stream);
+    msm_enqueue_batch<C>(ctx, d_out + first_column[k] * static_cast<size_t>(out_stride), out_stride,
+                         projective_out, batches[k], d_addends, d_api_generators, stream);
+  }
+}
+
+template <class C>
+void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                       const msm_plan& plan, const typename C::addend* d_addends,
+                       const void* d_api_generators, hipStream_t stream) {
+  using point = typename C::point;
+  using addend = typename C::addend;
+  const u32 num_tasks = static_cast<u32>(plan.tasks.size());
+  const u32 num_cols = static_cast<u32>(plan.columns.size());
+  const u32 partial_stride = partial_stride_of(plan);
 
   column_desc* d_cols = ctx.arena.take<column_desc>(num_cols);
   task_desc* d_tasks = ctx.arena.take<task_desc>(num_tasks + 1);

@@ -238,6 +238,22 @@ static __global__ void __launch_bounds__(kSortThreads)
 // bucket *starts* owns bucket_sums[bucket]; a lane that begins in the middle of a bucket writes
 // that first partial to heads[segment] instead (k_reduce adds the heads of a bucket to its sum).
 // Every lane therefore does at most kSegmentEntries additions, whatever the digit distribution.
+//
+// Skewed data (many equal scalars) makes one bucket span many whole segments.  Consecutive lanes
+// of a wavefront whose segments lie entirely inside the same bucket fold their partials with a
+// segmented shuffle reduction (taken only when such a run exists: wave-uniform branch), and only
+// the first lane of the run writes a head: `load_bucket` below applies the same geometric rule,
+// so a bucket of m entries costs its consumer m / (32 * 64) additions instead of m / 32.
+template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 delta) {
+  static_assert(sizeof(P) % 4 == 0);
+  P r;
+  const u32* src = reinterpret_cast<const u32*>(&v);
+  u32* dst = reinterpret_cast<u32*>(&r);
+#pragma unroll
+  for (u32 i = 0; i < sizeof(P) / 4; ++i) dst[i] = __shfl_down(src[i], delta, 64);
+  return r;
+}
+
 template <class C>
 __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_simd)
     k_accumulate(typename C::point* __restrict__ bucket_sums, typename C::point* __restrict__ heads,
@@ -255,6 +271,8 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   u32 b_end = ends[b];
   const u32 b_start = b == 0 ? 0 : ends[b - 1];
   bool owned = b_start == lo;
+  // the whole segment lies inside a bucket that started in an earlier segment
+  const bool whole = !owned && b_end >= lo + kSegmentEntries;
   const u32* idx = sorted + task.entry_base;
   typename C::point* sums = bucket_sums + task.bucket_base;
   typename C::point acc = C::identity();
@@ -286,22 +304,45 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
     if (i + 2 < hi) e_after = idx[i + 2];
     C::accumulate(acc, q, (e >> 31) != 0);
   }
+  // runs of `whole` lanes (necessarily of one bucket) -> one head per run and wavefront
+  const unsigned long long whole_mask = __ballot(whole);
+  const u32 lane = threadIdx.x & 63;
+  bool write_head = !owned;
+  if ((whole_mask & (whole_mask >> 1)) != 0) {
+    const u32 run = whole ? static_cast<u32>(__ffsll(static_cast<long long>(~(whole_mask >> lane)))) - 1 : 0;
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const typename C::point other = wave_shfl_down(acc, d);
+      if (whole && d < run) acc = C::add(acc, other);
+    }
+    if (whole && lane != 0 && ((whole_mask >> (lane - 1)) & 1) != 0) write_head = false;
+  }
   if (owned) {
     sums[b] = acc;
-  } else {
+  } else if (write_head) {
     heads[task.segment_base + seg] = acc;
   }
 }
 
 // complete sum of bucket b of a task: the owner's partial plus the heads of the following
-// segments the bucket extends into
+// segments the bucket extends into.  Whole segments of one wavefront (64 consecutive segments)
+// were folded into the first of them by k_accumulate.
 template <class C>
 __device__ __forceinline__ typename C::point
 load_bucket(const typename C::point* __restrict__ sums, const typename C::point* __restrict__ heads,
             u32 begin, u32 end, u32 b) {
   typename C::point v = sums[b];
   const u32 first = begin / kSegmentEntries, last = (end - 1) / kSegmentEntries;
-  for (u32 s = first + 1; s <= last; ++s) v = C::add(v, heads[s]);
+  const u32 after_whole = end / kSegmentEntries; // first segment not entirely below `end`
+  u32 s = first + 1;
+  while (s <= last) {
+    v = C::add(v, heads[s]);
+    if (s < after_whole) {
+      const u32 next_wave = (s / 64 + 1) * 64;
+      s = next_wave < after_whole ? next_wave : after_whole;
+    } else {
+      ++s;
+    }
+  }
   return v;
 }
 

@@ -76,6 +76,9 @@ struct msm_plan {
 
 struct msm_tuning {
   u32 max_window_bits = 16; // the LDS histogram holds 2^(c-1) 32-bit counters (128 KiB at c = 16)
+  // batching of many-column jobs: tasks per launch (grid.y) and device workspace per batch
+  size_t max_tasks_per_batch = 32768;
+  size_t max_workspace_bytes = size_t{64} << 30;
 };
 
 inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b); }

@@ -32,6 +32,12 @@ uint64_t bzamd_kernel_launch_count(void);
  * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
 void bzamd_reset_for_testing(void);
 
+/* Engine knobs of the current device's MSM context (GPU backend; 0 keeps the current value):
+ * cap on the window width c (2..16), and the batching limits for many-column jobs (tasks = column
+ * windows per launch, device workspace bytes per batch).  Results never depend on them. */
+void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
+                      uint64_t max_workspace_bytes);
+
 /* Per-stage device timing of the next `max_calls` MSM calls issued on the current device, measured
  * with HIP events on the launch stream.  `bzamd_stage_timing_collect` blocks until those calls
  * finished, writes the accumulated milliseconds of the six stages

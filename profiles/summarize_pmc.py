@@ -54,6 +54,20 @@ def main():
             vals = [f"{sum(counters[k][c]) / len(counters[k][c]):.4g}" if c in counters[k] else ""
                     for c in names]
             print(f"| {k} | " + " | ".join(meta[k]) + " | " + " | ".join(vals) + " |")
+        acc = [k for k in counters if k.startswith("k_accumulate")]
+        if acc and "FETCH_SIZE" in counters[acc[0]] and "WRITE_SIZE" in counters[acc[0]]:
+            import json
+            f = sum(counters[acc[0]]["FETCH_SIZE"]) / len(counters[acc[0]]["FETCH_SIZE"])
+            w = sum(counters[acc[0]]["WRITE_SIZE"]) / len(counters[acc[0]]["WRITE_SIZE"])
+            out = {"kernel": acc[0], "fetch_kib": f, "write_kib": w,
+                   "k_accumulate_bytes_per_launch": (f + w) * 1024,
+                   "note": "FETCH_SIZE + WRITE_SIZE (KiB) x 1024, separate --pmc passes; the "
+                           "gathers are per-lane 16-byte loads of random 144-byte rows, for which "
+                           "FETCH_SIZE matches the 64-byte-sector count of the rows (no x2 "
+                           "streaming correction applies), see DESIGN.md"}
+            if len(sys.argv) > 2:
+                with open(sys.argv[2], "w") as fh:
+                    json.dump(out, fh, indent=1)
         print("\nFETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts wide "
               "streaming reads at half their bytes (MI355X_MICROARCH.md, HBM section).")
 

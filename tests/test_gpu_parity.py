@@ -235,3 +235,52 @@ def test_row_sharded_fold_on_device(gpu_backend, oracle):
         got = api.fold_encode(curve_id, np.stack(parts))
         assert np.array_equal(got, oracle.commit(curve_id, cols, gens))
         _ = ctypes
+
+
+def test_skewed_and_batched_columns(gpu_backend, oracle):
+    """digit distributions that put most entries in one bucket (equal scalars, two values, all
+    ones, sparse) and many-column jobs split into several batches by the engine; results never
+    depend on the tuning knobs"""
+    api = gpu_backend
+    lib = api.load()
+    rng = np.random.default_rng(77)
+    n = 9000
+    gens = util.generators_for(0, n)
+    g = util.api_generators(0, gens)
+    one = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    two = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+    sparse = np.zeros((n, 32), np.uint8)
+    sparse[rng.integers(0, n, 40)] = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    cols = [(np.tile(one, (n, 1)), False), (two[rng.integers(0, 2, n)], False),
+            (np.full((n, 32), 0xff, np.uint8), False), (sparse, False),
+            (np.ones((n, 1), np.uint8), False), (rng.integers(0, 2, (n, 1), dtype=np.uint8), False)]
+    cols += [(rng.integers(0, 256, (n - 7 * k, 1 + (5 * k) % 32), dtype=np.uint8), False)
+             for k in range(30)]
+    want = oracle.commit(0, cols, gens)
+    assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
+    try:
+        lib.bzamd_set_tuning(11, 40, 0)          # narrower windows, ~3 columns per batch
+        assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
+        lib.bzamd_set_tuning(16, 32768, 1 << 20)  # 1 MiB of workspace: one column per batch
+        assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
+    finally:
+        lib.bzamd_set_tuning(16, 32768, 64 << 30)
+
+
+def test_skewed_long_column(gpu_backend):
+    """2^18 equal 252-bit scalars: every window has one bucket spanning 8192 segments"""
+    from tests import hooks
+    api = gpu_backend
+    n = 1 << 18
+    rng = np.random.default_rng(5)
+    s = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    s[0, 31] &= 0x0f
+    out = api.compute_pedersen_commitments(0, [(np.tile(s, (n, 1)), False)])
+    k = int.from_bytes(s[0].tobytes(), "little")
+    one_commit = api.get_one_commit(n)
+    acc = api.get_one_commit(0)
+    for bit in range(k.bit_length() - 1, -1, -1):
+        acc = hooks.ed_dbl(acc)
+        if (k >> bit) & 1:
+            acc = hooks.ed_add(acc, one_commit)
+    assert np.array_equal(hooks.ristretto_encode(acc), out[0])
