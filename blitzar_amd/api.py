@@ -115,6 +115,8 @@ def load():
     lib.bzamd_msm_device_resident.argtypes = [vp, u32, ctypes.POINTER(sxt_sequence_descriptor),
                                               vp, vp]
     lib.bzamd_msm_device_resident.restype = None
+    lib.bzamd_generator_multiples_device.argtypes = [cu, vp, vp, u64, vp]
+    lib.bzamd_generator_multiples_device.restype = None
     lib.bzamd_ristretto255_generators_device.argtypes = [vp, u64, u64, vp]
     lib.bzamd_ristretto255_generators_device.restype = None
     lib.bzamd_fixed_packed_multiexponentiation_device.argtypes = [vp, vp, vp, vp, cu, cu, vp, vp]

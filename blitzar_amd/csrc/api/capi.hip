@@ -676,6 +676,15 @@ void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
              static_cast<hipStream_t>(stream));
 }
 
+void bzamd_generator_multiples_device(unsigned curve_id, void* generators, const void* base,
+                                      uint64_t n, void* stream) {
+  const curve_vtable* vt = curve_vtable_for(curve_id);
+  BZ_RELEASE_ASSERT(vt != nullptr, "unknown curve id");
+  BZ_RELEASE_ASSERT(n == 0 || (generators != nullptr && base != nullptr), "null operand");
+  vt->generator_multiples(generators, base, n, static_cast<hipStream_t>(stream));
+  g_kernel_launches += 1;
+}
+
 void bzamd_ristretto255_generators_device(struct sxt_ristretto255* generators, uint64_t first,
                                           uint64_t n, void* stream) {
   BZ_RELEASE_ASSERT(n == 0 || generators != nullptr, "generators is null");

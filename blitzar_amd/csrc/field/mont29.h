@@ -1,0 +1,311 @@
+// Montgomery arithmetic on unsaturated 29-bit (28-bit for BLS12-381) limbs in 32-bit registers:
+// the representation the gfx950 kernels compute in for the three Weierstrass base fields.
+//
+// Why not the ABI's saturated 64-bit limbs (field/mont.h, kept for everything observable)?  gfx950
+// has one wide multiplier primitive, v_mad_u64_u32 (32 x 32 + 64 -> 64, 5.6 cycles per
+// wave-instruction).  With saturated limbs every partial product needs its carry moved by hand:
+// hipcc's lowering of the 4 x 64-bit CIOS costs ~130 mads plus ~870 v_addc / v_mov / s_nop per
+// product inside k_accumulate.  With LB-bit limbs (LB < 32) the 64-bit column accumulators absorb
+// 2N products without overflowing, so a product is 2 N^2 mads and ~N (4 VALU) of bookkeeping:
+//   bn254 / grumpkin  N = 9,  LB = 29, R = 2^261:  162 mads, ~260 instructions
+//   bls12-381         N = 14, LB = 28, R = 2^392:  392 mads, ~560 instructions
+// and additions are N carry-less v_add_u32 (values are reduced lazily).
+//
+// Values: an element x is held as an integer X = x * R mod p *plus a multiple of p*,
+//   X = sum_i v[i] * 2^(LB i),   0 <= X < V p.
+// Two bounds are tracked in the comments of every caller (curve/sw29.h):
+//   B = max limb / 2^LB   "normalised" means B <= 1 (top limb: whatever the value needs)
+//   V = X / p             P::max_v = floor(R / p) is the largest representable
+// Contracts (checked at run time in host builds with BZ_MONT29_CHECK, see tests/):
+//   mul(a, b):   N (B_a B_b + 1) <= 64  (i.e. B_a B_b <= 6 for N = 9, <= 3.5 for N = 14);
+//                V_a V_b <= max_v^2-ish such that the result fits; result normalised,
+//                V < V_a V_b / max_v + 1
+//   add(a, b):   limb-wise (B and V add up)
+//   sub<K>(a,b): a + K p - b with the limbs of K p inflated; needs every limb of b <= 2^(LB+1) - 2
+//                and V_b < K - 0.01; result B <= B_a + 3, V < V_a + K
+//   norm(a):     carry sweep, B <= 1, value unchanged
+//   reduce(a):   normalised in, normalised out with V < 4
+// Results only leave through canonical encodings (from / to the ABI's R = 2^(64 N64) form), so
+// this representation is unobservable.
+#pragma once
+
+#include "blitzar_amd/csrc/field/mont29_params.h"
+
+#if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+#define BZ_M29_ASSERT(cond, what)                                                                  \
+  do {                                                                                             \
+    if (!(cond)) {                                                                                 \
+      std::fprintf(stderr, "mont29 bound violated: %s (%s:%d)\n", what, __FILE__, __LINE__);      \
+      std::abort();                                                                                \
+    }                                                                                              \
+  } while (0)
+#else
+#define BZ_M29_ASSERT(cond, what) ((void)0)
+#endif
+
+namespace bz {
+
+template <int N> struct fe29m {
+  u32 v[N];
+};
+
+template <class P> struct mont29 {
+  static constexpr int N = P::N;
+  static constexpr int LB = P::LB;
+  static constexpr int N64 = P::N64;
+  static constexpr u32 kMask = (1u << LB) - 1;
+  static constexpr u32 max_v = P::max_v;
+  using fe = fe29m<N>;
+
+  BZ_HD static fe zero() {
+    fe h;
+#pragma unroll
+    for (int i = 0; i < N; ++i) h.v[i] = 0;
+    return h;
+  }
+
+  BZ_HD static fe one() {
+    fe h;
+#pragma unroll
+    for (int i = 0; i < N; ++i) h.v[i] = P::one(i);
+    return h;
+  }
+
+  BZ_HD static fe add(const fe& a, const fe& b) {
+    fe h;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      BZ_M29_ASSERT(static_cast<u64>(a.v[i]) + b.v[i] < (u64{1} << 32), "add overflows a limb");
+      h.v[i] = a.v[i] + b.v[i];
+    }
+    return h;
+  }
+
+  // carry sweep: every limb but the top below 2^LB; the value is unchanged
+  BZ_HD static fe norm(const fe& a) {
+    fe h;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+      const u64 t = static_cast<u64>(a.v[i]) + c;
+      h.v[i] = static_cast<u32>(t) & kMask;
+      c = static_cast<u32>(t >> LB);
+    }
+    BZ_M29_ASSERT(static_cast<u64>(a.v[N - 1]) + c < (u64{1} << 32), "norm overflows the top limb");
+    h.v[N - 1] = a.v[N - 1] + c;
+    return h;
+  }
+
+  template <int K> BZ_HD static constexpr u32 bias(int i) {
+    if constexpr (K == 2) return P::bias2(i);
+    if constexpr (K == 4) return P::bias4(i);
+    if constexpr (K == 8) return P::bias8(i);
+    if constexpr (K == 16) return P::bias16(i);
+    if constexpr (K == 32) return P::bias32(i);
+    if constexpr (K == 64) return P::bias64(i);
+    return 0;
+  }
+
+  // a - b + K p
+  template <int K> BZ_HD static fe sub(const fe& a, const fe& b) {
+    fe h;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      BZ_M29_ASSERT(b.v[i] <= bias<K>(i), "sub: a limb of b exceeds the bias");
+      BZ_M29_ASSERT(static_cast<u64>(a.v[i]) + bias<K>(i) < (u64{1} << 32), "sub overflows a limb");
+      h.v[i] = a.v[i] + bias<K>(i) - b.v[i];
+    }
+    return h;
+  }
+
+  template <int K = 2> BZ_HD static fe neg(const fe& a) { return sub<K>(zero(), a); }
+
+  BZ_HD static fe select(const fe& a, const fe& b, bool pick_b) {
+    fe h;
+#pragma unroll
+    for (int i = 0; i < N; ++i) h.v[i] = pick_b ? b.v[i] : a.v[i];
+    return h;
+  }
+
+  BZ_HD static u64 mad(u32 a, u32 b, u64 c) { return static_cast<u64>(a) * b + c; }
+
+#if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+  static void check_mul_operands(const fe& a, const fe& b) {
+    u64 ma = 0, mb = 0;
+    for (int i = 0; i < N; ++i) {
+      if (a.v[i] > ma) ma = a.v[i];
+      if (b.v[i] > mb) mb = b.v[i];
+    }
+    // every accumulator takes at most N products a_j b_i, N products m p_j and a carry
+    const unsigned __int128 worst =
+        static_cast<unsigned __int128>(N) * ma * mb +
+        static_cast<unsigned __int128>(N) * (u64{1} << LB) * (u64{1} << LB) + (u64{1} << 40);
+    BZ_M29_ASSERT(worst < (static_cast<unsigned __int128>(1) << 64), "mul: column accumulator overflow");
+  }
+#endif
+
+  // Montgomery product a b / R (mod p), coarsely integrated operand scanning on 64-bit column
+  // accumulators: per limb of b, N mads for a * b_i, one v_mul_lo for the quotient digit, N mads
+  // for m * p, and one shift that retires the (now zero) lowest column.
+  BZ_HD static fe mul(const fe& a, const fe& b) {
+#if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    check_mul_operands(a, b);
+#endif
+    u64 t[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) t[j] = mad(a.v[j], b.v[i], t[j]);
+      const u32 m = (static_cast<u32>(t[0]) * P::inv) & kMask;
+#pragma unroll
+      for (int j = 0; j < N; ++j) t[j] = mad(m, P::p(j), t[j]);
+      // t[0] is now a multiple of 2^LB: retire it
+      const u64 carry = t[0] >> LB;
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) t[j] = t[j + 1];
+      t[0] += carry;
+      t[N - 1] = 0;
+    }
+    fe h;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      h.v[j] = static_cast<u32>(t[j]) & kMask;
+      t[j + 1] += t[j] >> LB;
+    }
+    BZ_M29_ASSERT(t[N - 1] < (u64{1} << LB), "mul: result does not fit (V_a V_b too large)");
+    h.v[N - 1] = static_cast<u32>(t[N - 1]);
+    return h;
+  }
+
+  BZ_HD static fe sqr(const fe& a) { return mul(a, a); }
+
+  // a * c for a small constant c, normalised (V grows by the factor c)
+  BZ_HD static fe mul_small(const fe& a, u32 c) {
+    fe h;
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+      acc = mad(a.v[i], c, acc);
+      h.v[i] = static_cast<u32>(acc) & kMask;
+      acc >>= LB;
+    }
+    acc = mad(a.v[N - 1], c, acc);
+    BZ_M29_ASSERT(acc < (u64{1} << LB), "mul_small: result does not fit");
+    h.v[N - 1] = static_cast<u32>(acc);
+    return h;
+  }
+
+  // normalised a (top limb < 2^LB) -> normalised, same residue, V < 4
+  BZ_HD static fe reduce(const fe& a) {
+    BZ_M29_ASSERT(a.v[N - 1] < (1u << LB), "reduce: input not normalised");
+    // q underestimates floor(a / p) by at most 2
+    const u32 q = static_cast<u32>((static_cast<u64>(a.v[N - 1]) * P::top_magic) >> 32);
+    fe h;
+    i64 c = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+      const i64 t = static_cast<i64>(a.v[i]) + c - static_cast<i64>(static_cast<u64>(q) * P::p(i));
+      h.v[i] = static_cast<u32>(t) & kMask;
+      c = t >> LB;
+    }
+    const i64 t = static_cast<i64>(a.v[N - 1]) + c - static_cast<i64>(static_cast<u64>(q) * P::p(N - 1));
+    BZ_M29_ASSERT(t >= 0 && t < (i64{1} << LB), "reduce: quotient estimate out of range");
+    h.v[N - 1] = static_cast<u32>(t);
+    return h;
+  }
+
+  // the unique representative in [0, p) (input: any normalised element)
+  BZ_HD static fe canonical(const fe& a) {
+    fe r = reduce(a); // < 4 p
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+      fe d;
+      i64 c = 0;
+#pragma unroll
+      for (int i = 0; i < N - 1; ++i) {
+        const i64 t = static_cast<i64>(r.v[i]) + c - static_cast<i64>(P::p(i));
+        d.v[i] = static_cast<u32>(t) & kMask;
+        c = t >> LB;
+      }
+      const i64 t = static_cast<i64>(r.v[N - 1]) + c - static_cast<i64>(P::p(N - 1));
+      d.v[N - 1] = static_cast<u32>(t);
+      r = select(r, d, t >= 0);
+    }
+    return r;
+  }
+
+  BZ_HD static bool is_zero(const fe& a) {
+    const fe r = canonical(norm(a));
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc |= r.v[i];
+    return acc == 0;
+  }
+
+  // limbs of an integer < 2^(64 N64) given as little-endian 64-bit words
+  BZ_HD static fe from_words(const u64* w) {
+    fe h;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int bit = LB * i;
+      const int word = bit >> 6, sh = bit & 63;
+      u64 v = word < N64 ? w[word] >> sh : 0;
+      if (sh + LB > 64 && word + 1 < N64) v |= w[word + 1] << (64 - sh);
+      h.v[i] = i == N - 1 ? static_cast<u32>(v) : static_cast<u32>(v) & kMask;
+    }
+    return h;
+  }
+
+  // little-endian 64-bit words of a canonical (fully reduced, normalised) element
+  BZ_HD static void to_words(u64* w, const fe& a) {
+#pragma unroll
+    for (int k = 0; k < N64; ++k) w[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int bit = LB * i;
+      const int word = bit >> 6, sh = bit & 63;
+      if (word < N64) w[word] |= static_cast<u64>(a.v[i]) << sh;
+      if (sh + LB > 64 && word + 1 < N64) w[word + 1] |= static_cast<u64>(a.v[i]) >> (64 - sh);
+    }
+  }
+
+  // ABI Montgomery form (x * 2^(64 N64) mod p, canonical 64-bit limbs) -> this representation
+  BZ_HD static fe from_mont64(const u64* w) {
+    fe c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) c.v[i] = P::c_in(i);
+    return mul(from_words(w), c);
+  }
+
+  // this representation -> ABI Montgomery form, canonical
+  BZ_HD static void to_mont64(u64* w, const fe& a) {
+    fe c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) c.v[i] = P::c_out(i);
+    to_words(w, canonical(mul(a, c)));
+  }
+
+  // a^(p-2); zero for zero.  `a` normalised with V < 8.
+  BZ_HD_NOINLINE static fe invert(const fe& a) {
+    // exponent bits from the limbs of p (p - 2 only changes limb 0, which is >= 2 for all moduli)
+    fe acc = one();
+    for (int i = N - 1; i >= 0; --i) {
+      const u32 e = i == 0 ? P::p(0) - 2 : P::p(i);
+      const int top = i == N - 1 ? 31 - __builtin_clz(P::p(N - 1)) : LB - 1;
+      for (int b = top; b >= 0; --b) {
+        acc = sqr(acc);
+        if ((e >> b) & 1) acc = mul(acc, a);
+      }
+    }
+    return acc;
+  }
+};
+
+using bn254_fq29 = mont29<bn254_fq29_params>;
+using grumpkin_fq29 = mont29<grumpkin_fq29_params>;
+using bls12_381_fp28 = mont29<bls12_381_fp28_params>;
+} // namespace bz

@@ -77,19 +77,20 @@ template <> struct compact_ops<ed25519_msm> {
   }
 };
 
+// ABI-form (saturated 64-bit Montgomery) arithmetic: table entries are canonical by construction
 template <class C> struct sw_compact_ops {
-  static constexpr int N = C::N;
-  using F = typename C::F;
+  using G = typename C::G64;
+  using F = typename G::F;
+  static constexpr int N = F::N;
   using compact = sw_compact<N>;
-  using point = typename C::point;
-  static point identity() { return C::identity(); }
+  using point = typename G::point;
+  static point identity() { return G::identity(); }
   static bool is_identity(const compact& c) { return c.X.v[N - 1] == ~u64{0}; }
   static point expand(const compact& c) {
-    if (is_identity(c)) return C::identity();
+    if (is_identity(c)) return G::identity();
     return {c.X, c.Y, F::one()};
   }
   static compact shrink(const point& p) {
-    typename C::addend a;
     compact c;
     if (F::is_zero(p.Z)) {
       c.X = F::zero();
@@ -97,12 +98,13 @@ template <class C> struct sw_compact_ops {
       c.Y = F::one();
       return c;
     }
-    a = C::addend_from_point(p);
+    typename G::affine a;
+    (void)G::to_affine(a, p);
     c.X = a.x;
     c.Y = a.y;
     return c;
   }
-  static point add(const point& p, const point& q) { return C::add(p, q); }
+  static point add(const point& p, const point& q) { return G::add(p, q); }
 };
 template <> struct compact_ops<bn254_msm> : sw_compact_ops<bn254_msm> {};
 template <> struct compact_ops<grumpkin_msm> : sw_compact_ops<grumpkin_msm> {};

@@ -9,6 +9,7 @@
 #include "blitzar_amd/csrc/curve/ed25519.h"
 #include "blitzar_amd/csrc/curve/ed29.h"
 #include "blitzar_amd/csrc/curve/ed29_coop.h"
+#include "blitzar_amd/csrc/curve/sw29.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
 
 namespace bz {
@@ -61,6 +62,8 @@ struct ed25519_msm {
   BZ_HD static point point_from_api_projective(const void* projective, u64 i) {
     return ed29::from_ed(static_cast<const ed_point*>(projective)[i]);
   }
+  // engine point -> caller generator layout (sxt_ristretto255)
+  BZ_HD static void store_api_generator(u8* out, const point& p) { store_projective(out, p); }
   // k_combine's dependent chain, run by all 64 lanes of one wavefront with the four lanes of
   // every DPP quad sharing each doubling / addition (curve/ed29_coop.h):
   //   sum_w 2^(c w) * window_sums[w * stride]
@@ -79,92 +82,75 @@ struct ed25519_msm {
 #endif
 };
 
-template <class G, unsigned CurveId> struct sw_msm_base {
+// Weierstrass curves: the kernels compute on the unsaturated-limb Montgomery representation
+// (field/mont29.h, curve/sw29.h); the ABI's saturated 64-bit Montgomery limbs only appear where
+// generators enter and where a result leaves (conversions + the existing ABI-form encoders).
+template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr unsigned curve_id = CurveId;
-  static constexpr int N = G::N;
-  using F = typename G::F;
-  using point = typename G::point;
-  using addend = typename G::affine; // (0, 0) marks the identity (never on y^2 = x^3 + b, b != 0)
-  using api_projective = point;      // sxt_*_p2 / element_p2
-  using api_affine = sw_api_affine<N>;
+  using G64 = typename G29::G64;       // ABI-form curve (curve/weierstrass.h)
+  using F64 = typename G64::F;
+  static constexpr int N64 = F64::N;
+  using point = typename G29::point;
+  using addend = typename G29::affine; // (0, 0) marks the identity (never on y^2 = x^3 + b, b != 0)
+  using api_projective = typename G64::point; // sxt_*_p2 / element_p2
+  using api_affine = sw_api_affine<N64>;
   static constexpr size_t api_generator_size = sizeof(api_affine);
-  static constexpr size_t projective_size = sizeof(point);
-  static constexpr int accumulate_waves_per_simd = 1;
+  static constexpr size_t projective_size = sizeof(api_projective);
+  static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
   static constexpr bool has_wave_horner = false;
 
-  BZ_HD static point identity() { return G::identity(); }
-  BZ_HD static point add(const point& a, const point& b) { return G::add(a, b); }
-  BZ_HD static point dbl_n(const point& a, int k) { return G::dbl_n(a, k); }
-  BZ_HD static point neg(const point& a) { return G::neg(a); }
+  BZ_HD static point identity() { return G29::identity(); }
+  BZ_HD static point add(const point& a, const point& b) { return G29::add(a, b); }
+  BZ_HD static point dbl_n(const point& a, int k) { return G29::dbl_n(a, k); }
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
-    if (F::is_zero(q.x) && F::is_zero(q.y)) return;
-    addend t = q;
-    t.y = F::cneg(q.y, negate);
-    acc = G::add_mixed(acc, t);
+    if (G29::is_identity_addend(q)) return;
+    acc = G29::add_mixed(acc, q, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];
-    addend a;
-    for (int k = 0; k < N; ++k) {
-      a.x.v[k] = g.infinity ? 0 : g.X[k];
-      a.y.v[k] = g.infinity ? 0 : g.Y[k];
-    }
-    return a;
+    return G29::affine_from_mont64(g.X, g.Y, g.infinity != 0);
   }
-  BZ_HD static addend addend_from_point(const point& p) {
-    addend a;
-    if (G::to_affine(a, p)) {
-      a.x = F::zero();
-      a.y = F::zero();
-    }
-    return a;
-  }
-  // the ABI's projective element (element_p2) is the engine's point type for these curves
+  // handle generators: ABI projective element -> affine (one inversion, ABI-form arithmetic)
   BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {
-    return addend_from_point(static_cast<const point*>(projective)[i]);
+    typename G64::affine a;
+    const bool inf = G64::to_affine(a, static_cast<const api_projective*>(projective)[i]);
+    return G29::affine_from_mont64(a.x.v, a.y.v, inf);
   }
   BZ_HD static point point_from_api_projective(const void* projective, u64 i) {
-    return static_cast<const point*>(projective)[i];
-  }
-  BZ_HD static point point_from_api(const void* api_generators, u64 i) {
-    const api_affine& g = static_cast<const api_affine*>(api_generators)[i];
-    if (g.infinity) return G::identity();
-    point p;
-    for (int k = 0; k < N; ++k) {
-      p.X.v[k] = g.X[k];
-      p.Y.v[k] = g.Y[k];
-    }
-    p.Z = F::one();
-    return p;
+    return G29::from_point64(static_cast<const api_projective*>(projective)[i]);
   }
   BZ_HD static void store_projective(u8* out, const point& p) {
-    *reinterpret_cast<point*>(out) = p;
+    *reinterpret_cast<api_projective*>(out) = G29::to_point64(p);
   }
+  // engine point -> caller generator layout ({X, Y, u8 infinity} at the C-ABI stride)
+  BZ_HD static void store_api_generator(u8* out, const point& p) { encode_affine(out, p); }
   // {X, Y Montgomery, u8 infinity}; identity = {0, R, 1}
   BZ_HD static void encode_affine(u8* out, const point& p) {
-    typename G::affine a;
-    const bool inf = G::to_affine(a, p);
+    typename G64::affine a;
+    const bool inf = G64::to_affine(a, G29::to_point64(p));
     u64* o = reinterpret_cast<u64*>(out);
-    for (int k = 0; k < N; ++k) {
+    for (int k = 0; k < N64; ++k) {
       o[k] = a.x.v[k];
-      o[N + k] = a.y.v[k];
+      o[N64 + k] = a.y.v[k];
     }
-    o[2 * N] = inf ? 1 : 0; // infinity byte + zeroed struct padding
+    o[2 * N64] = inf ? 1 : 0; // infinity byte + zeroed struct padding
   }
 };
 
-struct bn254_msm : sw_msm_base<bn254_g1, 2> {
+struct bn254_msm : sw_msm_base<bn254_g1_29, 2> {
   static constexpr size_t output_size = 72; // sxt_bn254_g1
   BZ_HD static void encode(u8* out, const point& p) { encode_affine(out, p); }
 };
 
-struct grumpkin_msm : sw_msm_base<grumpkin_g, 3> {
+struct grumpkin_msm : sw_msm_base<grumpkin_29, 3> {
   static constexpr size_t output_size = 72; // sxt_grumpkin
   BZ_HD static void encode(u8* out, const point& p) { encode_affine(out, p); }
 };
 
-struct bls12_381_msm : sw_msm_base<bls12_381_g1, 1> {
+struct bls12_381_msm : sw_msm_base<bls12_381_g1_28, 1> {
   static constexpr size_t output_size = 48; // sxt_bls12_381_g1_compressed
-  BZ_HD static void encode(u8* out, const point& p) { bls12_381_g1_compress(out, p); }
+  BZ_HD static void encode(u8* out, const point& p) {
+    bls12_381_g1_compress(out, bls12_381_g1_28::to_point64(p));
+  }
 };
 } // namespace bz

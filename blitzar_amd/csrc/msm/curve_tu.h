@@ -33,6 +33,24 @@ __global__ void __launch_bounds__(64)
   C::encode(out + static_cast<u64>(k) * C::output_size, acc);
 }
 
+// out[i] = (i + 1) * base in the curve's C-ABI generator layout: large synthetic generator sets
+// with known discrete logarithms (bench / full-size parity checks; the reference's
+// generate_random_element costs a 255-bit scalar multiplication per point on the host)
+template <class C>
+__global__ void __launch_bounds__(64)
+    k_generator_multiples(u8* __restrict__ out, const void* __restrict__ base_api, u64 n) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const typename C::addend g = C::make_addend(base_api, 0);
+  typename C::point acc = C::identity();
+  const u64 k = i + 1;
+  for (int bit = 63 - __builtin_clzll(k); bit >= 0; --bit) {
+    acc = C::dbl_n(acc, 1);
+    if ((k >> bit) & 1) C::accumulate(acc, g, false);
+  }
+  C::store_api_generator(out + i * C::api_generator_size, acc);
+}
+
 template <class C> struct curve_tu {
   static void msm(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                   const std::vector<host_column>& cols, const void* d_addends,
@@ -85,6 +103,12 @@ template <class C> struct curve_tu {
                        num_outputs);
     BZ_HIP_CHECK(hipGetLastError());
   }
+  static void generator_multiples(void* d_out, const void* d_base_api, u64 n, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL((k_generator_multiples<C>), dim3(ceil_div_u32(n, 64)), dim3(64), 0, stream,
+                       static_cast<u8*>(d_out), d_base_api, n);
+    BZ_HIP_CHECK(hipGetLastError());
+  }
   static const curve_vtable& vtable() {
     static const curve_vtable vt{C::curve_id,
                                  C::api_generator_size,
@@ -97,6 +121,7 @@ template <class C> struct curve_tu {
                                  &curve_tu::msm_host_entry,
                                  &curve_tu::fold_encode_host,
                                  &curve_tu::fold_encode_device,
+                                 &curve_tu::generator_multiples,
                                  sizeof(typename compact_ops<C>::compact),
                                  &write_partition_table<C>,
                                  &read_partition_generators<C>};

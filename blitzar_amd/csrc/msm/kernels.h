@@ -475,16 +475,21 @@ __global__ void __launch_bounds__(kCombineThreads)
       }
     }
   } else {
-    if (tid == 0) {
+    // all lanes of the first wavefront run the chain redundantly: keeping the data in vector
+    // registers stops hipcc from moving the whole multi-limb chain onto the scalar unit (it did:
+    // s_mul_hi_u32 chains with hundreds of SGPR spills, ~3x slower than the VALU form)
+    if (tid < 64) {
       point acc = tree[(W - 1) * team];
       for (u32 wi = W - 1; wi-- > 0;) {
         acc = C::dbl_n(acc, static_cast<int>(col.window_bits));
         acc = C::add(acc, tree[wi * team]);
       }
-      if (projective_out) {
-        C::store_projective(dst, acc);
-      } else {
-        C::encode(dst, acc);
+      if (tid == 0) {
+        if (projective_out) {
+          C::store_projective(dst, acc);
+        } else {
+          C::encode(dst, acc);
+        }
       }
     }
   }

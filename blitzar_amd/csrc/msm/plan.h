@@ -79,20 +79,29 @@ struct msm_tuning {
   // batching of many-column jobs: tasks per launch (grid.y) and device workspace per batch
   size_t max_tasks_per_batch = 32768;
   size_t max_workspace_bytes = size_t{64} << 30;
+  // window-width cost model: from this many columns on, buckets cost `throughput_bucket_cost`
+  size_t throughput_columns = 4;
+  double throughput_bucket_cost = 12.0;
 };
 
 inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b); }
 
 // choose the window width for a column of n rows and B significant bits: minimise
-// point additions = W * (n + 2.5 * 2^(c-1)) with W = ceil((B + 1) / c)
-inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune) {
+//   W * (n + bucket_cost * 2^(c-1)),  W = ceil((B + 1) / c)
+// where bucket_cost is the price of reducing one bucket in units of one bucket addition.  A
+// single column is latency-bound in k_reduce (few waves, the dependent chain is what matters): its
+// buckets are nearly free (2.5).  Many columns fill the machine with reduce work (measured on
+// MI355X, bn254, 32 x 2^20: 2.5 ns per bucket against 0.16 ns per addition), so buckets are priced
+// at their throughput cost and narrower windows win.
+inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune, double bucket_cost = 2.5) {
   u32 best_c = 1;
   double best_cost = 1e300;
   const u32 cmax = tune.max_window_bits < bits + 1 ? tune.max_window_bits : bits + 1;
   for (u32 c = 2; c <= cmax; ++c) {
     const u32 w = ceil_div_u32(bits + 1, c);
     const double cost =
-        static_cast<double>(w) * (static_cast<double>(n) + 2.5 * static_cast<double>(1u << (c - 1)));
+        static_cast<double>(w) *
+        (static_cast<double>(n) + bucket_cost * static_cast<double>(1u << (c - 1)));
     if (cost < best_cost) {
       best_cost = cost;
       best_c = c;
@@ -118,6 +127,9 @@ inline host_column byte_column(const u8* data, u64 n, u32 nbytes, bool is_signed
 inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tuning& tune = {}) {
   msm_plan plan;
   plan.columns.reserve(cols.size());
+  size_t nonempty = 0;
+  for (const auto& c : cols) nonempty += c.n != 0 ? 1 : 0;
+  const double bucket_cost = nonempty >= tune.throughput_columns ? tune.throughput_bucket_cost : 2.5;
   for (size_t ci = 0; ci < cols.size(); ++ci) {
     const host_column& hc = cols[ci];
     column_desc cd{};
@@ -135,7 +147,7 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       continue;
     }
     const u32 bits = hc.bit_width;
-    const u32 c = choose_window_bits(hc.n, bits, tune);
+    const u32 c = choose_window_bits(hc.n, bits, tune, bucket_cost);
     const u32 w = ceil_div_u32(bits + 1, c);
     const u32 buckets = 1u << (c - 1);
     const u32 slices = ceil_div_u32(hc.n, kSliceRows);

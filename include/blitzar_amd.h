@@ -94,6 +94,12 @@ void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
 void bzamd_ristretto255_generators_device(struct sxt_ristretto255* generators, uint64_t first,
                                           uint64_t n, void* stream);
 
+/* DEVICE generators[i] = (i + 1) * base in the curve's C-ABI generator layout, base = one DEVICE
+ * generator in the same layout (async).  Synthetic generator sets with known discrete logarithms
+ * for benchmarks and full-size parity checks. */
+void bzamd_generator_multiples_device(unsigned curve_id, void* generators, const void* base,
+                                      uint64_t n, void* stream);
+
 /* Fixed-base (handle) MSM with DEVICE scalars and DEVICE results; same packing rules as
  * sxt_fixed_packed_multiexponentiation / sxt_fixed_vlen_multiexponentiation
  * (output_lengths may be NULL = all rows). */

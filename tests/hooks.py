@@ -197,3 +197,30 @@ def ed29_chain(points, negate):
     neg = _c(negate, np.int32)
     lib().bz_ed29_chain(_p(out), _p(pts), _p(neg), ctypes.c_int(pts.shape[0]))
     return out
+
+
+def sw29_field(cid, op, *args):
+    out = np.zeros(LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_29_field_{op}")(_p(out), *[_p(_c(a)) for a in args])
+    return out
+
+
+def sw29_add(cid, a, b):
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_29_add")(_p(out), _p(_c(a)), _p(_c(b)))
+    return out
+
+
+def sw29_dbl_n(cid, a, k):
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    getattr(lib(), f"bz_{PFX[cid]}_29_dbl_n")(_p(out), _p(_c(a)), ctypes.c_int(k))
+    return out
+
+
+def sw29_chain(cid, start, affine_xy, negate):
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    xy = _c(affine_xy)
+    neg = _c(negate, np.int32)
+    getattr(lib(), f"bz_{PFX[cid]}_29_chain")(_p(out), _p(_c(start)), _p(xy), _p(neg),
+                                              ctypes.c_int(xy.shape[0]))
+    return out

@@ -1,10 +1,12 @@
 // Test-only C hooks over the product's header-only field/curve code (host compilation), so that
 // the CPU test-suite can compare it limb-for-limb with the reference oracle (oracle/_ref).
 // Built by __graft_entry__.build() into tests/native/_build/libbz_hooks.so.
+#define BZ_MONT29_CHECK 1
 #include <cstring>
 
 #include "blitzar_amd/csrc/curve/ed25519.h"
 #include "blitzar_amd/csrc/curve/ed29.h"
+#include "blitzar_amd/csrc/curve/sw29.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
 #include "blitzar_amd/csrc/msm/plan.h"
 #include "blitzar_amd/csrc/msm/recode.h"
@@ -251,4 +253,48 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
   ed_point e = ed29::to_ed(acc);
   std::memcpy(out, &e, 160);
 }
+
+// unsaturated-limb Montgomery fields / curves of the gfx950 kernels (field/mont29.h,
+// curve/sw29.h), driven through their ABI-form conversions; built with BZ_MONT29_CHECK so every
+// limb-level contract is asserted while the tests run
+#define BZ_SW29_HOOKS(PFX, G)                                                                      \
+  void bz_##PFX##_29_field_mul(u64* h, const u64* f, const u64* g) {                               \
+    G::F::to_mont64(h, G::F::mul(G::F::from_mont64(f), G::F::from_mont64(g)));                     \
+  }                                                                                                \
+  void bz_##PFX##_29_field_roundtrip(u64* h, const u64* f) {                                       \
+    G::F::to_mont64(h, G::F::from_mont64(f));                                                      \
+  }                                                                                                \
+  void bz_##PFX##_29_field_invert(u64* h, const u64* f) {                                          \
+    G::F::to_mont64(h, G::F::invert(G::F::from_mont64(f)));                                        \
+  }                                                                                                \
+  void bz_##PFX##_29_add(u64* out, const u64* a, const u64* b) {                                   \
+    G::G64::point p, q;                                                                            \
+    std::memcpy(&p, a, sizeof(p));                                                                 \
+    std::memcpy(&q, b, sizeof(q));                                                                 \
+    G::G64::point r = G::to_point64(G::add(G::from_point64(p), G::from_point64(q)));               \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }                                                                                                \
+  void bz_##PFX##_29_dbl_n(u64* out, const u64* a, int k) {                                        \
+    G::G64::point p;                                                                               \
+    std::memcpy(&p, a, sizeof(p));                                                                 \
+    G::G64::point r = G::to_point64(G::dbl_n(G::from_point64(p), k));                              \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }                                                                                                \
+  /* acc = start + sum_i (+-) q_i with mixed additions; q_i affine {x, y} ABI form */              \
+  void bz_##PFX##_29_chain(u64* out, const u64* start, const u64* affine_xy, const int* negate,    \
+                           int n) {                                                                \
+    G::G64::point p;                                                                               \
+    std::memcpy(&p, start, sizeof(p));                                                             \
+    G::point acc = G::from_point64(p);                                                             \
+    constexpr int W = G::N64;                                                                      \
+    for (int i = 0; i < n; ++i) {                                                                  \
+      G::affine q = G::affine_from_mont64(affine_xy + 2 * W * i, affine_xy + 2 * W * i + W, false); \
+      acc = G::add_mixed(acc, q, negate[i] != 0);                                                  \
+    }                                                                                              \
+    G::G64::point r = G::to_point64(acc);                                                          \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }
+BZ_SW29_HOOKS(bn254, bn254_g1_29)
+BZ_SW29_HOOKS(grumpkin, grumpkin_29)
+BZ_SW29_HOOKS(bls12_381, bls12_381_g1_28)
 }

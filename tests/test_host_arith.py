@@ -253,3 +253,79 @@ def test_ed29_group_law_matches_reference(oracle):
     for q, s in zip(g, signs):
         acc = hooks.ed_sub(acc, q) if s else oracle.add_projective(0, acc, q)
     assert np.array_equal(canon(hooks.ed29_chain(g, signs)), canon(acc))
+
+
+#--------------------------------------------------------------------------------------------------
+# unsaturated-limb Montgomery fields / Weierstrass curves of the gfx950 kernels
+# (field/mont29.h, curve/sw29.h); the hook library asserts the limb contracts (BZ_MONT29_CHECK)
+#--------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cid", [1, 2, 3])
+def test_mont29_field_matches_reference(oracle, cid):
+    rng = np.random.default_rng(50 + cid)
+    pfx, nl = oracle.CURVES[cid][0], oracle.CURVES[cid][1]
+    gens = util.weierstrass_generators(cid, 20, distinct_seeds=20)
+    elems = [gens[i, :8 * nl].view(np.uint64) for i in range(20) if i != 5]
+    elems += [gens[i, 8 * nl:16 * nl].view(np.uint64) for i in range(20) if i != 5]
+    elems.append(np.zeros(nl, np.uint64))
+    one = oracle.identity_affine(cid)[8 * nl:16 * nl].view(np.uint64)  # R mod p
+    elems.append(one)
+    lib = oracle.lib()
+    for f in elems:
+        assert np.array_equal(hooks.sw29_field(cid, "roundtrip", f), f)
+    for _ in range(150):
+        f = elems[int(rng.integers(len(elems)))]
+        g = elems[int(rng.integers(len(elems)))]
+        want = np.zeros(nl, np.uint64)
+        getattr(lib, f"ref_{pfx}_field_mul")(want.ctypes.data_as(ctypes.c_void_p),
+                                             f.ctypes.data_as(ctypes.c_void_p),
+                                             g.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(hooks.sw29_field(cid, "mul", f, g), want)
+    for f in elems[:6]:
+        inv = hooks.sw29_field(cid, "invert", f)
+        assert np.array_equal(hooks.sw29_field(cid, "mul", f, inv), one)
+
+
+@pytest.mark.parametrize("cid", [1, 2, 3])
+def test_sw29_group_law_matches_reference(oracle, cid):
+    nl = oracle.CURVES[cid][1]
+    gens = util.weierstrass_generators(cid, 40, distinct_seeds=12)
+    proj = oracle.affine_to_projective(cid, gens)
+    ident = proj[5]
+    canon = lambda p: oracle.to_affine(cid, p)  # noqa: E731
+    for i in (0, 1, 2, 3, 6, 7):
+        a, b = proj[i], proj[i + 1]
+        assert np.array_equal(canon(hooks.sw29_add(cid, a, b)), canon(oracle.add_projective(cid, a, b)))
+        assert np.array_equal(canon(hooks.sw29_add(cid, a, a)), canon(oracle.double_projective(cid, a)))
+        assert np.array_equal(canon(hooks.sw29_add(cid, a, ident)), canon(a))
+        assert np.array_equal(canon(hooks.sw29_add(cid, ident, a)), canon(a))
+        d = a
+        for k in range(1, 18):
+            d = oracle.double_projective(cid, d)
+            if k in (1, 2, 16, 17):
+                assert np.array_equal(canon(hooks.sw29_dbl_n(cid, a, k)), canon(d))
+    assert np.array_equal(canon(hooks.sw29_dbl_n(cid, ident, 3)), canon(ident))
+    # a long signed accumulation chain from the identity (what one bucket lane does), with
+    # repeated points (complete formulas: doubling and cancellation inside the chain)
+    rng = np.random.default_rng(60 + cid)
+    order = [i for i in range(40) if i != 5]
+    order = order + order[:7] + order[:3]
+    signs = rng.integers(0, 2, len(order))
+    signs[-3:] = 1 - signs[:3]  # the last three cancel the first three
+    acc = ident
+    for i, s in zip(order, signs):
+        q = proj[i].copy()
+        if s:
+            neg = oracle.add_projective(cid, ident, q)  # copy
+            # -q: negate Y via the oracle: 0 - q is not exposed, use p - y through canonical affine
+            aff = oracle.to_affine(cid, q).copy()
+            y = int.from_bytes(aff[8 * nl:16 * nl].tobytes(), "little")
+            pmod = {1: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+                    2: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+                    3: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}[cid]
+            aff[8 * nl:16 * nl] = np.frombuffer(((pmod - y) % pmod).to_bytes(8 * nl, "little"), np.uint8)
+            q = oracle.affine_to_projective(cid, aff)[0]
+            del neg
+        acc = oracle.add_projective(cid, acc, q)
+    xy = np.stack([gens[i, :16 * nl].view(np.uint64) for i in order])
+    got = hooks.sw29_chain(cid, ident, xy, signs)
+    assert np.array_equal(canon(got), canon(acc))
