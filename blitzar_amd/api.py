@@ -19,7 +19,8 @@ SXT_CURVE_BN_254 = 2
 SXT_CURVE_GRUMPKIN = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libblitzar_amd.so")
+# BLITZAR_AMD_LIB selects another build of the same library (kernel-variant A/B runs)
+LIB_PATH = os.environ.get("BLITZAR_AMD_LIB") or os.path.join(_HERE, "lib", "libblitzar_amd.so")
 
 # per curve: (C-ABI generator stride, commitment bytes, projective element bytes)
 CURVE_LAYOUT = {

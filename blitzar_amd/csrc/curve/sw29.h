@@ -167,6 +167,21 @@ template <class P> struct sw29 {
     return r;
   }
 
+  // canonical affine coordinates in ABI form; identity -> (0, R) and true, as the reference's
+  // to_element_affine (curve_bng1/type/conversion_utility.h:45-62).  One inversion, done on the
+  // unsaturated limbs (a^(p-2): ~1.5 N LB products).
+  BZ_HD static bool to_affine64(typename G64::affine& a, const point& p) {
+    const bool inf = F::is_zero(p.Z);
+    const fe zinv = F::invert(p.Z);
+    F::to_mont64(a.x.v, F::mul(p.X, zinv));
+    F::to_mont64(a.y.v, F::mul(p.Y, zinv));
+    if (inf) {
+      a.x = G64::F::zero();
+      a.y = G64::F::one();
+    }
+    return inf;
+  }
+
   // affine ABI coordinates -> addend; identity -> (0, 0)
   BZ_HD static affine affine_from_mont64(const u64* x, const u64* y, bool infinity) {
     affine a;

@@ -168,10 +168,8 @@ using grumpkin_g = sw<grumpkin_params>;
 // 48-byte compressed bls12-381 G1 encoding (zkcrypto serialization; reference
 // sxt/curve_g1/operation/compression.cc:34-59): big-endian x with flag bits
 // 7 = compressed, 6 = infinity, 5 = y lexicographically largest.
-BZ_HD void bls12_381_g1_compress(u8 out[48], const bls12_381_g1::point& p) {
+BZ_HD void bls12_381_g1_compress_affine(u8 out[48], const bls12_381_g1::affine& a, bool inf) {
   using F = bls12_381_fp;
-  bls12_381_g1::affine a;
-  const bool inf = bls12_381_g1::to_affine(a, p);
   F::fe x = inf ? F::zero() : F::from_mont(a.x);
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 8; ++j) out[8 * (5 - i) + (7 - j)] = static_cast<u8>(x.v[i] >> (8 * j));
@@ -190,5 +188,11 @@ BZ_HD void bls12_381_g1_compress(u8 out[48], const bls12_381_g1::point& p) {
     borrow = static_cast<u64>(d >> 64) & 1;
   }
   if (borrow == 0) out[0] |= 0x20;
+}
+
+BZ_HD void bls12_381_g1_compress(u8 out[48], const bls12_381_g1::point& p) {
+  bls12_381_g1::affine a;
+  const bool inf = bls12_381_g1::to_affine(a, p);
+  bls12_381_g1_compress_affine(out, a, inf);
 }
 } // namespace bz

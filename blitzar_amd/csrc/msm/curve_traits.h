@@ -38,7 +38,10 @@ struct ed25519_msm {
   static constexpr size_t projective_size = 160;    // element_p3 (fixed-base results)
   // register budget of k_accumulate: 3 waves per SIMD = at most 168 VGPRs (accumulator, current
   // addend, prefetched next addend, product temporaries)
-  static constexpr int accumulate_waves_per_simd = 3;
+#ifndef BZ_ED_ACC_WAVES
+#define BZ_ED_ACC_WAVES 3
+#endif
+  static constexpr int accumulate_waves_per_simd = BZ_ED_ACC_WAVES;
 
   BZ_HD static point identity() { return ed29::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return ed29::add(a, b); }
@@ -127,7 +130,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   // {X, Y Montgomery, u8 infinity}; identity = {0, R, 1}
   BZ_HD static void encode_affine(u8* out, const point& p) {
     typename G64::affine a;
-    const bool inf = G64::to_affine(a, G29::to_point64(p));
+    const bool inf = G29::to_affine64(a, p);
     u64* o = reinterpret_cast<u64*>(out);
     for (int k = 0; k < N64; ++k) {
       o[k] = a.x.v[k];
@@ -150,7 +153,9 @@ struct grumpkin_msm : sw_msm_base<grumpkin_29, 3> {
 struct bls12_381_msm : sw_msm_base<bls12_381_g1_28, 1> {
   static constexpr size_t output_size = 48; // sxt_bls12_381_g1_compressed
   BZ_HD static void encode(u8* out, const point& p) {
-    bls12_381_g1_compress(out, bls12_381_g1_28::to_point64(p));
+    bls12_381_g1::affine a;
+    const bool inf = bls12_381_g1_28::to_affine64(a, p);
+    bls12_381_g1_compress_affine(out, a, inf);
   }
 };
 } // namespace bz
