@@ -172,10 +172,13 @@ def main():
             # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command
             # (tools/prof/run_pmc.sh -> profiles/roofline_traffic.json); null until collected
             traffic = None
+            valu_busy = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath) and args.log2n is None:
                 with open(tpath) as fh:
-                    traffic = json.load(fh).get("k_accumulate_bytes_per_launch")
+                    pmc = json.load(fh)
+                traffic = pmc.get("k_accumulate_bytes_per_launch")
+                valu_busy = pmc.get("valu_busy")
             result["roofline"] = {
                 "kernel": "k_accumulate<ed25519>",
                 "bound": "hbm",
@@ -186,6 +189,9 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": per_call["accumulate"],
+                # the binding bound of this kernel is integer issue, not HBM:
+                # fraction of cycles the SIMDs' VALU was issuing, from the same PMC run
+                "valu_busy": valu_busy,
             }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_log2n)

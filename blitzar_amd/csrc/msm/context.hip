@@ -1,4 +1,6 @@
 // msm_context lifetime + curve id dispatch.
+#include <cstdlib>
+
 #include "blitzar_amd/csrc/msm/dispatch.h"
 #include "blitzar_amd/csrc/msm/engine.h"
 

@@ -67,18 +67,22 @@ struct ed25519_msm {
   }
   // engine point -> caller generator layout (sxt_ristretto255)
   BZ_HD static void store_api_generator(u8* out, const point& p) { store_projective(out, p); }
-  // k_combine's dependent chain, run by all 64 lanes of one wavefront with the four lanes of
+  // k_horner's dependent chain, run by all 64 lanes of one wavefront with the four lanes of
   // every DPP quad sharing each doubling / addition (curve/ed29_coop.h):
-  //   sum_w 2^(c w) * window_sums[w * stride]
+  //   2^(c n) * acc + sum_{w < n} 2^(c w) * window_sums[w * stride]   (acc absent: top window first)
   static constexpr bool has_wave_horner = true;
 #if defined(__HIPCC__)
-  __device__ static point wave_horner(const point* window_sums, u32 stride, u32 num_windows,
-                                      u32 window_bits) {
+  __device__ static point wave_horner(point acc, bool have_acc, const point* window_sums,
+                                      u32 stride, u32 num_windows, u32 window_bits) {
     const u32 role = threadIdx.x & 3;
-    point acc = window_sums[(num_windows - 1) * stride];
-    for (u32 wi = num_windows - 1; wi-- > 0;) {
+    u32 i = num_windows;
+    if (!have_acc) {
+      acc = window_sums[(num_windows - 1) * stride];
+      i = num_windows - 1;
+    }
+    while (i-- > 0) {
       for (u32 k = 0; k < window_bits; ++k) acc = ed29::dbl_coop4(acc, role);
-      acc = ed29::add_cached_coop4(acc, ed29::to_cached(window_sums[wi * stride]), role);
+      acc = ed29::add_cached_coop4(acc, ed29::to_cached(window_sums[i * stride]), role);
     }
     return acc;
   }

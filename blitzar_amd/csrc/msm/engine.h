@@ -11,44 +11,59 @@
 
 namespace bz {
 
-// Optional per-stage device timing (HIP events on the launch stream), used by bench.py to report
-// the dominant kernel's measured duration next to its algorithmic bytes.
+// Optional per-stage device timing (HIP event pairs on the launch stream), used by bench.py to
+// report the dominant kernel's measured duration next to its algorithmic bytes.
 constexpr int kNumStages = 6; // prepare, recode, sort, accumulate, reduce, combine
 struct stage_timer {
+  struct span {
+    int stage;
+    hipEvent_t begin, end;
+  };
   bool enabled = false;
-  std::vector<hipEvent_t> events; // (kNumStages + 1) per recorded call
+  std::vector<span> spans;
   size_t calls = 0;
   size_t capacity_calls = 0;
 
   void begin(size_t max_calls) {
     release();
-    events.resize(max_calls * (kNumStages + 1));
-    for (auto& e : events) BZ_HIP_CHECK(hipEventCreate(&e));
     capacity_calls = max_calls;
     calls = 0;
     enabled = true;
   }
-  hipEvent_t event(int stage) { return events[calls * (kNumStages + 1) + stage]; }
   bool recording() const { return enabled && calls < capacity_calls; }
+  // bracket `launch()` with an event pair on `stream`
+  template <class F> void timed(bool on, int stage, hipStream_t stream, F&& launch) {
+    if (!on) {
+      launch();
+      return;
+    }
+    span sp{stage, nullptr, nullptr};
+    BZ_HIP_CHECK(hipEventCreate(&sp.begin));
+    BZ_HIP_CHECK(hipEventCreate(&sp.end));
+    BZ_HIP_CHECK(hipEventRecord(sp.begin, stream));
+    launch();
+    BZ_HIP_CHECK(hipEventRecord(sp.end, stream));
+    spans.push_back(sp);
+  }
   // accumulated milliseconds per stage over the recorded calls (blocks until they finished)
   size_t collect(double out_ms[kNumStages]) {
     for (int s = 0; s < kNumStages; ++s) out_ms[s] = 0;
-    for (size_t c = 0; c < calls; ++c) {
-      hipEvent_t* ev = &events[c * (kNumStages + 1)];
-      BZ_HIP_CHECK(hipEventSynchronize(ev[kNumStages]));
-      for (int s = 0; s < kNumStages; ++s) {
-        float ms = 0;
-        BZ_HIP_CHECK(hipEventElapsedTime(&ms, ev[s], ev[s + 1]));
-        out_ms[s] += ms;
-      }
+    for (auto& sp : spans) {
+      BZ_HIP_CHECK(hipEventSynchronize(sp.end));
+      float ms = 0;
+      BZ_HIP_CHECK(hipEventElapsedTime(&ms, sp.begin, sp.end));
+      out_ms[sp.stage] += ms;
     }
     const size_t n = calls;
     release();
     return n;
   }
   void release() {
-    for (auto& e : events) (void)hipEventDestroy(e);
-    events.clear();
+    for (auto& sp : spans) {
+      (void)hipEventDestroy(sp.begin);
+      (void)hipEventDestroy(sp.end);
+    }
+    spans.clear();
     enabled = false;
     calls = 0;
     capacity_calls = 0;
@@ -96,6 +111,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
   need += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
+  need += device_arena::padded(sizeof(point) * (num_cols + 1));
   return need;
 }
 
@@ -168,6 +184,24 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   }
 }
 
+// device arrays of one batch
+template <class C> struct batch_buffers {
+  column_desc* cols;
+  task_desc* tasks;
+  const typename C::addend* addends;
+  i16* digits;
+  u32* sorted;
+  u32* hist;
+  u32* chunk_totals;
+  u32* segment_bucket;
+  u32* bucket_end;
+  typename C::point* bucket_sums;
+  typename C::point* heads;
+  typename C::point* partials;
+  typename C::point* horner_state;
+  u32 partial_stride;
+};
+
 template <class C>
 void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const msm_plan& plan, const typename C::addend* d_addends,
@@ -176,80 +210,83 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   using addend = typename C::addend;
   const u32 num_tasks = static_cast<u32>(plan.tasks.size());
   const u32 num_cols = static_cast<u32>(plan.columns.size());
-  const u32 partial_stride = partial_stride_of(plan);
-
-  column_desc* d_cols = ctx.arena.take<column_desc>(num_cols);
-  task_desc* d_tasks = ctx.arena.take<task_desc>(num_tasks + 1);
-  BZ_HIP_CHECK(hipMemcpyAsync(d_cols, plan.columns.data(), sizeof(column_desc) * num_cols,
+  batch_buffers<C> b{};
+  b.partial_stride = partial_stride_of(plan);
+  b.cols = ctx.arena.take<column_desc>(num_cols);
+  b.tasks = ctx.arena.take<task_desc>(num_tasks + 1);
+  BZ_HIP_CHECK(hipMemcpyAsync(b.cols, plan.columns.data(), sizeof(column_desc) * num_cols,
                               hipMemcpyHostToDevice, stream));
-  if (num_tasks > 0) {
-    BZ_HIP_CHECK(hipMemcpyAsync(d_tasks, plan.tasks.data(), sizeof(task_desc) * num_tasks,
-                                hipMemcpyHostToDevice, stream));
+  if (num_tasks == 0) {
+    // every column is empty: identities only
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
+                       out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
+                       static_cast<const point*>(nullptr), 1u, b.cols, 0u, 0u, 1, 1);
+    g_kernel_launches += 1;
+    BZ_HIP_CHECK(hipGetLastError());
+    return;
   }
+  BZ_HIP_CHECK(hipMemcpyAsync(b.tasks, plan.tasks.data(), sizeof(task_desc) * num_tasks,
+                              hipMemcpyHostToDevice, stream));
+  const bool timing = ctx.timer.recording();
+  if (d_addends == nullptr) {
+    addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
+    ctx.timer.timed(timing, 0, stream, [&] {
+      hipLaunchKernelGGL((k_prepare_addends<C>), dim3(ceil_div_u32(plan.max_rows, 256)), dim3(256),
+                         0, stream, prepared, d_api_generators, plan.max_rows);
+    });
+    d_addends = prepared;
+  }
+  b.addends = d_addends;
+  b.digits = ctx.arena.take<i16>(plan.total_entries + 8);
+  b.sorted = ctx.arena.take<u32>(plan.total_entries + 8);
+  b.hist = ctx.arena.take<u32>(plan.total_hist + 2);
+  b.chunk_totals = ctx.arena.take<u32>(plan.total_chunks + 1);
+  b.segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
+  b.bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
+  b.bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
+  b.heads = ctx.arena.take<point>(plan.total_segments + 1);
+  b.partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * b.partial_stride + 1);
+  b.horner_state = ctx.arena.take<point>(num_cols);
+  const size_t sort_lds = sizeof(u32) * plan.max_task_buckets;
+  const u32 seg_blocks =
+      ceil_div_u32(plan.max_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
 
-  const bool timing = ctx.timer.recording() && num_tasks > 0;
-  auto mark = [&](int stage) {
-    if (timing) BZ_HIP_CHECK(hipEventRecord(ctx.timer.event(stage), stream));
-  };
-  if (num_tasks > 0) {
-    mark(0);
-    if (d_addends == nullptr) {
-      addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
-      const u32 blocks = ceil_div_u32(plan.max_rows, 256);
-      hipLaunchKernelGGL((k_prepare_addends<C>), dim3(blocks), dim3(256), 0, stream, prepared,
-                         d_api_generators, plan.max_rows);
-      d_addends = prepared;
-    }
-    i16* d_digits = ctx.arena.take<i16>(plan.total_entries + 8);
-    u32* d_sorted = ctx.arena.take<u32>(plan.total_entries + 8);
-    u32* d_hist = ctx.arena.take<u32>(plan.total_hist + 2);
-    u32* d_chunk_totals = ctx.arena.take<u32>(plan.total_chunks + 1);
-    u32* d_segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
-    u32* d_bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
-    point* d_bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
-    point* d_heads = ctx.arena.take<point>(plan.total_segments + 1);
-    point* d_partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * partial_stride + 1);
-
-    mark(1);
+  // One stream, stages in order.  (Running the sort of window group k+1 and the reduce / Horner of
+  // group k-1 on side streams under the accumulation of group k was measured on MI355X and is
+  // slower, 1.94 -> 2.0-2.3 ms at config 2: k_accumulate's waves hold 480 of a SIMD's 512 VGPRs,
+  // so side kernels only get slots as accumulate waves retire and both sides lose.)
+  ctx.timer.timed(timing, 1, stream, [&] {
     hipLaunchKernelGGL(k_recode, dim3(ceil_div_u32(plan.max_rows, 256), num_cols), dim3(256), 0,
-                       stream, d_digits, d_cols, d_tasks);
-    mark(2);
-
-    // counting sort by bucket
-    BZ_HIP_CHECK(hipMemsetAsync(d_chunk_totals, 0, sizeof(u32) * (plan.total_chunks + 1), stream));
-    const size_t sort_lds = sizeof(u32) * plan.max_task_buckets;
+                       stream, b.digits, b.cols, b.tasks);
+  });
+  BZ_HIP_CHECK(hipMemsetAsync(b.chunk_totals, 0, sizeof(u32) * (plan.total_chunks + 1), stream));
+  ctx.timer.timed(timing, 2, stream, [&] {
     hipLaunchKernelGGL(k_bucket_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       sort_lds, stream, d_hist, d_chunk_totals, d_digits, d_tasks);
+                       sort_lds, stream, b.hist, b.chunk_totals, b.digits, b.tasks);
     hipLaunchKernelGGL(k_bucket_offsets,
                        dim3(ceil_div_u32(plan.max_task_buckets, kOffsetChunkBuckets), num_tasks),
-                       dim3(256), 0, stream, d_hist, d_bucket_end, d_chunk_totals, d_tasks);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(plan.max_task_slices, num_tasks),
-                       dim3(kSortThreads), sort_lds, stream, d_sorted, d_segment_bucket, d_hist,
-                       d_digits, d_tasks);
-    mark(3);
-
-    const u32 seg_blocks =
-        ceil_div_u32(plan.max_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
+                       dim3(256), 0, stream, b.hist, b.bucket_end, b.chunk_totals, b.tasks);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
+                       sort_lds, stream, b.sorted, b.segment_bucket, b.hist, b.digits, b.tasks);
+  });
+  ctx.timer.timed(timing, 3, stream, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
-                       stream, d_bucket_sums, d_heads, d_bucket_end, d_segment_bucket, d_sorted,
-                       d_addends, d_tasks);
-    mark(4);
-
-    hipLaunchKernelGGL((k_reduce<C>), dim3(partial_stride, num_tasks), dim3(kReduceThreads), 0,
-                       stream, d_partials, partial_stride, d_bucket_sums, d_heads, d_bucket_end,
-                       d_tasks);
-    mark(5);
-
-    hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
-                       out_stride, projective_out ? 1 : 0, d_partials, partial_stride, d_cols);
-    mark(6);
-    if (timing) ctx.timer.calls += 1;
-  } else {
-    // every column is empty: identities only
-    hipLaunchKernelGGL((k_combine<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
-                       out_stride, projective_out ? 1 : 0, nullptr, partial_stride, d_cols);
-  }
-  g_kernel_launches += num_tasks > 0 ? 7 : 1;
+                       stream, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
+                       b.addends, b.tasks);
+  });
+  ctx.timer.timed(timing, 4, stream, [&] {
+    hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
+                       stream, b.partials, b.partial_stride, b.bucket_sums, b.heads, b.bucket_end,
+                       b.tasks);
+  });
+  // whole columns in one launch: the range covers every window, first and last
+  ctx.timer.timed(timing, 5, stream, [&] {
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
+                       out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
+                       b.partial_stride, b.cols, 0u, 0xffffffffu, 1, 1);
+  });
+  if (timing) ctx.timer.calls += 1;
+  g_kernel_launches += 7;
   BZ_HIP_CHECK(hipGetLastError());
 }
 

@@ -19,7 +19,7 @@
 //                       accumulation_kernel.h:37-75: one thread per bucket)
 //   k_reduce           per task: sum_b (b + 1) * bucket[b]  (reference K4 bucket_method2/reduce.h:50-78,
 //                      K8 + host combine_buckets bucket_method/combination.h:27-63)
-//   k_combine          per column: Horner over windows, canonical encoding
+//   k_horner           per column (and window range): Horner over windows, canonical encoding
 //                      (reference: host rsto::batch_compress / batch_to_element_affine,
 //                       sxt/cbindings/backend/cpu_backend.cc:117-152)
 //
@@ -417,30 +417,40 @@ __global__ void __launch_bounds__(kReduceThreads)
 }
 
 //--------------------------------------------------------------------------------------------------
-// k_combine
+// k_horner
 //--------------------------------------------------------------------------------------------------
-// One workgroup per column: fold the per-(window, block) partials into one sum per window (all
-// windows concurrently, a power-of-two team of lanes per window), then the Horner recurrence
-// acc = 2^c acc + window[w]  from the top window down -- on one lane, or on one wavefront when the
-// curve has a lane-cooperative form of the chain (C::wave_horner) -- and the canonical encoding
-// (or the raw projective point when `projective_out`).
+// One workgroup per column, windows [w_lo, w_hi) of it: fold the per-(window, block) partials into
+// one sum per window (all windows concurrently, a power-of-two team of lanes per window), then the
+// Horner recurrence  acc = 2^c acc + window[w]  from the top window of the range down -- on one
+// wavefront (all lanes redundantly, or lane-cooperatively when the curve offers C::wave_horner).
+// `first`: the range contains the column's top window (no incoming state); otherwise the chain
+// continues from state[column].  `last`: the range ends at window 0: write the canonical encoding
+// (or the raw projective point when `projective_out`); otherwise leave the chain value in
+// state[column].  The whole column in one launch = first && last with the full range.
 template <class C>
 __global__ void __launch_bounds__(kCombineThreads)
-    k_combine(u8* __restrict__ out, u32 out_stride, int projective_out,
-              const typename C::point* __restrict__ partials, u32 partial_stride,
-              const column_desc* __restrict__ columns) {
+    k_horner(u8* __restrict__ out, u32 out_stride, int projective_out,
+             typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
+             u32 partial_stride, const column_desc* __restrict__ columns, u32 w_lo_arg, u32 w_hi_arg,
+             int first, int last) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
   const column_desc col = columns[blockIdx.x];
   const u32 tid = threadIdx.x;
   u8* dst = out + static_cast<u64>(blockIdx.x) * out_stride;
-  const u32 W = col.num_windows;
+  const u32 w_hi = w_hi_arg < col.num_windows ? w_hi_arg : col.num_windows;
+  const u32 w_lo = w_lo_arg < w_hi ? w_lo_arg : w_hi;
+  const u32 W = w_hi - w_lo;
   if (W == 0) {
+    // nothing to add in this range (empty column, or a range above the column's top window)
     if (tid == 0) {
-      if (projective_out) {
-        C::store_projective(dst, C::identity());
+      const point acc = first ? C::identity() : state[blockIdx.x];
+      if (!last) {
+        state[blockIdx.x] = acc;
+      } else if (projective_out) {
+        C::store_projective(dst, acc);
       } else {
-        C::encode(dst, C::identity());
+        C::encode(dst, acc);
       }
     }
     return;
@@ -454,7 +464,7 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 blocks = (nb + kReduceBlockBuckets - 1) / kReduceBlockBuckets;
   point sum = C::identity();
   if (w < W) {
-    const point* p = partials + static_cast<u64>(col.first_task + w) * partial_stride;
+    const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;
     for (u32 blk = lane; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
   }
   tree[tid] = sum;
@@ -463,33 +473,34 @@ __global__ void __launch_bounds__(kCombineThreads)
     if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
     __syncthreads();
   }
-  if constexpr (C::has_wave_horner) {
-    if (tid < 64) {
-      const point acc = C::wave_horner(tree, team, W, col.window_bits);
-      if (tid == 0) {
-        if (projective_out) {
-          C::store_projective(dst, acc);
-        } else {
-          C::encode(dst, acc);
-        }
+  // all lanes of the first wavefront run the chain: keeping the data in vector registers stops
+  // hipcc from moving the multi-limb chain onto the scalar unit (it did: s_mul_hi_u32 chains with
+  // hundreds of SGPR spills, ~3x slower than the VALU form)
+  if (tid < 64) {
+    point acc;
+    if constexpr (C::has_wave_horner) {
+      acc = C::wave_horner(first ? C::identity() : state[blockIdx.x], first == 0, tree, team, W,
+                           col.window_bits);
+    } else {
+      u32 i = W;
+      if (first) {
+        acc = tree[(W - 1) * team];
+        i = W - 1;
+      } else {
+        acc = state[blockIdx.x];
+      }
+      while (i-- > 0) {
+        acc = C::dbl_n(acc, static_cast<int>(col.window_bits));
+        acc = C::add(acc, tree[i * team]);
       }
     }
-  } else {
-    // all lanes of the first wavefront run the chain redundantly: keeping the data in vector
-    // registers stops hipcc from moving the whole multi-limb chain onto the scalar unit (it did:
-    // s_mul_hi_u32 chains with hundreds of SGPR spills, ~3x slower than the VALU form)
-    if (tid < 64) {
-      point acc = tree[(W - 1) * team];
-      for (u32 wi = W - 1; wi-- > 0;) {
-        acc = C::dbl_n(acc, static_cast<int>(col.window_bits));
-        acc = C::add(acc, tree[wi * team]);
-      }
-      if (tid == 0) {
-        if (projective_out) {
-          C::store_projective(dst, acc);
-        } else {
-          C::encode(dst, acc);
-        }
+    if (tid == 0) {
+      if (!last) {
+        state[blockIdx.x] = acc;
+      } else if (projective_out) {
+        C::store_projective(dst, acc);
+      } else {
+        C::encode(dst, acc);
       }
     }
   }

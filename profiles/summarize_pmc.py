@@ -59,7 +59,15 @@ def main():
             import json
             f = sum(counters[acc[0]]["FETCH_SIZE"]) / len(counters[acc[0]]["FETCH_SIZE"])
             w = sum(counters[acc[0]]["WRITE_SIZE"]) / len(counters[acc[0]]["WRITE_SIZE"])
-            out = {"kernel": acc[0], "fetch_kib": f, "write_kib": w,
+            c = counters[acc[0]]
+            valu_busy = None
+            if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+                # quad-cycles of VALU issue summed over 1024 SIMDs / (cycles per XCD x SIMDs);
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                act = sum(c["SQ_ACTIVE_INST_VALU"]) / len(c["SQ_ACTIVE_INST_VALU"])
+                cyc = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8
+                valu_busy = 4 * act / (1024 * cyc)
+            out = {"kernel": acc[0], "fetch_kib": f, "write_kib": w, "valu_busy": valu_busy,
                    "k_accumulate_bytes_per_launch": (f + w) * 1024,
                    "note": "FETCH_SIZE + WRITE_SIZE (KiB) x 1024, separate --pmc passes; the "
                            "gathers are per-lane 16-byte loads of random 144-byte rows, for which "

@@ -284,3 +284,44 @@ def test_skewed_long_column(gpu_backend):
         if (k >> bit) & 1:
             acc = hooks.ed_add(acc, one_commit)
     assert np.array_equal(hooks.ristretto_encode(acc), out[0])
+
+
+def test_device_resident_entry_points(gpu_backend, oracle):
+    """include/blitzar_amd.h: operands already in HBM (torch tensors only provide the memory),
+    resident generator sets reused across calls, caller-provided stream"""
+    import ctypes
+    import torch
+    api = gpu_backend
+    lib = api.load()
+    dev = torch.device("cuda", 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(21)
+    for curve_id in (0, 2):
+        n = 3000
+        gens = util.generators_for(curve_id, n)
+        g_host = np.ascontiguousarray(util.api_generators(curve_id, gens))
+        cols = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False),
+                (rng.integers(0, 256, (n - 5, 4), dtype=np.uint8), True)]
+        want = oracle.commit(curve_id, cols, gens)
+        d_cols = [torch.from_numpy(c.copy()).to(dev) for c, _ in cols]
+        desc = (api.sxt_sequence_descriptor * 2)()
+        for i, ((c, s), d) in enumerate(zip(cols, d_cols)):
+            desc[i] = api.sxt_sequence_descriptor(c.shape[1], c.shape[0], d.data_ptr(), int(s))
+        d_gens = torch.from_numpy(g_host.copy()).to(dev)
+        out = torch.zeros((2, want.shape[1]), dtype=torch.uint8, device=dev)
+        lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 2, desc,
+                             ctypes.c_void_p(d_gens.data_ptr()), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        for maker in ("host", "device"):
+            if maker == "host":
+                h = lib.bzamd_generators_new_host(curve_id, g_host.ctypes.data_as(ctypes.c_void_p), n)
+            else:
+                h = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(d_gens.data_ptr()), n,
+                                                    stream)
+            out.zero_()
+            for _ in range(2):  # reused across calls
+                lib.bzamd_msm_device_resident(ctypes.c_void_p(out.data_ptr()), 2, desc, h, stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+            lib.bzamd_generators_free(h)
