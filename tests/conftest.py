@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# torch ships its own libamdhip64; a process that loads /opt/rocm's copy first (through
+# libblitzar_amd.so) cannot initialise torch.cuda afterwards ("No HIP GPUs are available").  The
+# tests that hand torch-allocated device memory to the C ABI therefore need torch loaded first;
+# the library itself never depends on torch.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

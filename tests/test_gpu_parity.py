@@ -325,3 +325,47 @@ def test_device_resident_entry_points(gpu_backend, oracle):
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), want)
             lib.bzamd_generators_free(h)
+
+
+@pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
+def test_random_sweep_matches_oracle(gpu_backend, oracle, curve_id):
+    """the randomized part of the reference exerciser (sxt/multiexp/test/multiexponentiation.cc:
+    290-451) through the HIP path: 1-10 sequences, length 0-100, 1-32 byte scalars, alternating
+    signedness"""
+    api = gpu_backend
+    rng = np.random.default_rng(8000 + curve_id)
+    gens = util.generators_for(curve_id, 100)
+    g = util.api_generators(curve_id, gens)
+    for _ in range(6):
+        cols = []
+        for s in range(int(rng.integers(1, 11))):
+            signed = bool(s % 2)
+            nb = int(rng.choice([1, 2, 4, 8, 16])) if signed else int(rng.integers(1, 33))
+            cols.append((rng.integers(0, 256, (int(rng.integers(0, 101)), nb), dtype=np.uint8),
+                         signed))
+        got = api.compute_pedersen_commitments(curve_id, cols, generators=g)
+        assert np.array_equal(got, oracle.commit(curve_id, cols, gens))
+
+
+@pytest.mark.parametrize("curve_id", [1, 2, 3])
+def test_repeated_and_cancelling_generators(gpu_backend, oracle, curve_id):
+    """degenerate inputs for the complete addition formulas: every generator the same point
+    (bucket sums are repeated doublings), and pairs that cancel to the identity"""
+    api = gpu_backend
+    rng = np.random.default_rng(8100 + curve_id)
+    n = 600
+    base = util.generators_for(curve_id, 8)
+    gens = np.tile(base[1], (n, 1))
+    g = util.api_generators(curve_id, gens)
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    same = np.tile(a[:1], (n, 1))
+    # x and -x on the same point: signed 8-byte column with values v, -v, v, -v ...
+    v = rng.integers(1, 2**62, n // 2, dtype=np.int64)
+    pm = np.empty(n, np.int64)
+    pm[0::2], pm[1::2] = v, -v
+    cols = [(a, False), (same, False), (pm, True), (np.ones((n, 1), np.uint8), False)]
+    got = api.compute_pedersen_commitments(curve_id, cols, generators=g)
+    want = oracle.commit(curve_id, cols, gens)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[2], oracle.commit(curve_id, [(np.zeros((0, 1), np.uint8), False)],
+                                                gens)[0])  # cancels to the identity encoding
