@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "blitzar_amd/csrc/api/state.h"
+#include "blitzar_amd/csrc/fixed/dump.h"
 #include "blitzar_amd/csrc/fixed/handle.h"
 #include "include/blitzar_amd.h"
 
@@ -372,10 +373,28 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   }
   const u32 out_stride = static_cast<u32>(h.vt->projective_size);
 
+  // BLITZAR_DUMP_DIR: record packed / vlen calls with host operands (the plain byte-aligned entry
+  // point is not recorded by the reference either, gpu_backend.cc:257-272)
+  std::unique_ptr<dump_recorder> recorder;
+  if (bit_table != nullptr && !device_operands) {
+    recorder = std::make_unique<dump_recorder>(lengths != nullptr ? "vlen-multiexponentiation"
+                                                                   : "packed-multiexponentiation");
+    if (recorder->recording()) {
+      recorder->write_inputs(h, bit_table, lengths, num_outputs, max_len, scalars,
+                             static_cast<size_t>(row_bytes) * max_len);
+    }
+  }
+  auto record_result = [&] {
+    if (recorder && recorder->recording()) {
+      recorder->write("result.bin", res, static_cast<size_t>(out_stride) * num_outputs);
+    }
+  };
+
   if (st.backend == SXT_CPU_BACKEND) {
     BZ_RELEASE_ASSERT(!device_operands, "device entry points need the GPU backend");
     h.vt->msm_host(static_cast<u8*>(res), out_stride, true, cols, h.host_projective.data(), true,
                    max_len);
+    record_result();
     return;
   }
   if (device_operands) {
@@ -398,6 +417,7 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   h.vt->msm(*st.ctx, d_out, out_stride, true, cols, h.d_addends, nullptr, st.stream);
   BZ_HIP_CHECK(hipMemcpyAsync(res, d_out, out_bytes, hipMemcpyDeviceToHost, st.stream));
   BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
+  record_result();
 }
 } // namespace
 

@@ -148,6 +148,18 @@ void write_partition_table(std::FILE* f, unsigned w, const void* projective_gene
   }
 }
 
+// the first n generators as compact elements (what the reference's accessor.copy_generators
+// yields: table entry 2^i of each window, in_memory_partition_table_accessor.h:69-82)
+template <class C>
+void write_compact_generators(std::FILE* f, const void* projective_generators, u64 n) {
+  using ops = compact_ops<C>;
+  const auto* g = static_cast<const typename ops::point*>(projective_generators);
+  for (u64 i = 0; i < n; ++i) {
+    const typename ops::compact c = ops::shrink(g[i]);
+    std::fwrite(&c, sizeof(c), 1, f);
+  }
+}
+
 // returns false on a malformed file; generators (projective) are appended to `out`
 template <class C>
 bool read_partition_generators(std::FILE* f, unsigned& w, std::vector<u8>& out, u64& n) {

@@ -33,6 +33,9 @@ struct ed25519_msm {
   using point = ed29_point;
   using addend = ed29_cached;
   using api_projective = ed_point; // sxt_ristretto255 / c21t::element_p3
+  // Itanium-mangled names of the reference types (meta.txt of a BLITZAR_DUMP_DIR recording)
+  static constexpr const char* reference_element_name = "N3sxt4c21t10element_p3E";
+  static constexpr const char* reference_compact_name = "N3sxt4c21t15compact_elementE";
   static constexpr size_t api_generator_size = 160; // sxt_ristretto255
   static constexpr size_t output_size = 32;         // sxt_ristretto255_compressed
   static constexpr size_t projective_size = 160;    // element_p3 (fixed-base results)
@@ -145,16 +148,22 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
 };
 
 struct bn254_msm : sw_msm_base<bn254_g1_29, 2> {
+  static constexpr const char* reference_element_name = "N3sxt4cn1t10element_p2E";
+  static constexpr const char* reference_compact_name = "N3sxt4cn1t15compact_elementE";
   static constexpr size_t output_size = 72; // sxt_bn254_g1
   BZ_HD static void encode(u8* out, const point& p) { encode_affine(out, p); }
 };
 
 struct grumpkin_msm : sw_msm_base<grumpkin_29, 3> {
+  static constexpr const char* reference_element_name = "N3sxt4cgkt10element_p2E";
+  static constexpr const char* reference_compact_name = "N3sxt4cgkt15compact_elementE";
   static constexpr size_t output_size = 72; // sxt_grumpkin
   BZ_HD static void encode(u8* out, const point& p) { encode_affine(out, p); }
 };
 
 struct bls12_381_msm : sw_msm_base<bls12_381_g1_28, 1> {
+  static constexpr const char* reference_element_name = "N3sxt4cg1t10element_p2E";
+  static constexpr const char* reference_compact_name = "N3sxt4cg1t15compact_elementE";
   static constexpr size_t output_size = 48; // sxt_bls12_381_g1_compressed
   BZ_HD static void encode(u8* out, const point& p) {
     bls12_381_g1::affine a;

@@ -124,7 +124,10 @@ template <class C> struct curve_tu {
                                  &curve_tu::generator_multiples,
                                  sizeof(typename compact_ops<C>::compact),
                                  &write_partition_table<C>,
-                                 &read_partition_generators<C>};
+                                 &read_partition_generators<C>,
+                                 &write_compact_generators<C>,
+                                 C::reference_element_name,
+                                 C::reference_compact_name};
     return vt;
   }
 };

@@ -43,6 +43,10 @@ struct curve_vtable {
   void (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);
   bool (*read_partition_generators)(std::FILE* f, unsigned& window_width,
                                     std::vector<u8>& projective_out, u64& n);
+  // BLITZAR_DUMP_DIR recording (fixed/dump.h): compact generators + the reference's type names
+  void (*write_compact_generators)(std::FILE* f, const void* projective, u64 n);
+  const char* element_type_name;  // typeid(T).name() of the reference's projective element
+  const char* accessor_type_name; // typeid(U).name() of its compact element
 };
 
 const curve_vtable& curve25519_vtable();

@@ -104,3 +104,40 @@ def test_partition_table_file_interop(cpu_backend, oracle, cid, tmp_path, monkey
                                         GOLDEN[f"curve{cid}_fixed_scalars"])
     assert np.array_equal(canon(oracle, cid, res), GOLDEN[f"curve{cid}_fixed_canonical"])
     h2.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_dump_dir_record_and_replay(cpu_backend, oracle, cid, tmp_path, monkeypatch):
+    """BLITZAR_DUMP_DIR writes the reference's recording layout
+    (multiexponentiation_serialization.h:70-103, gpu_backend.cc:286-301,317-332); the recording
+    replays to the same result, and its generators.bin is the reference's compact form"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import replay_dump
+    from oracle import fixed_base
+    proj = GOLDEN[f"curve{cid}_fixed_projective_generators"]
+    monkeypatch.setenv("BLITZAR_DUMP_DIR", str(tmp_path))
+    h = cpu_backend.MultiexpHandle(cid, proj)
+    n = proj.shape[0]
+    h.packed_multiexponentiation(GOLDEN["fixed_bit_table"], n, GOLDEN[f"curve{cid}_fixed_scalars"])
+    bt, lengths = [4, 12, 1], [0, 5, n]
+    s = np.random.default_rng(1).integers(0, 256, (n, 3), dtype=np.uint8)
+    h.vlen_multiexponentiation(bt, lengths, s)
+    h.close()
+    monkeypatch.delenv("BLITZAR_DUMP_DIR")
+    dirs = sorted(os.listdir(tmp_path))
+    assert [d.rsplit("-", 1)[0] for d in dirs] == ["packed-multiexponentiation",
+                                                   "vlen-multiexponentiation"]
+    packed = tmp_path / dirs[0]
+    assert sorted(os.listdir(packed)) == ["generators.bin", "meta.txt", "output_bit_table.bin",
+                                          "result.bin", "scalars.bin", "window_width.bin"]
+    assert "output_lengths.bin" in os.listdir(tmp_path / dirs[1])
+    # generators.bin == entries 2^i of the reference's partition table (copy_generators)
+    table = fixed_base.PartitionTable(cid, proj, 4)
+    want = np.stack([table.entries[((i // 4) << 4) + (1 << (i % 4))] for i in range(n)])
+    got = np.fromfile(packed / "generators.bin", np.uint8).reshape(n, -1)
+    assert np.array_equal(got, want)
+    assert np.fromfile(packed / "window_width.bin", np.uint64).tolist() == [16]
+    for d in dirs:
+        assert replay_dump.replay(str(tmp_path / d), cpu_backend.SXT_CPU_BACKEND)[2]
