@@ -266,8 +266,17 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     hipLaunchKernelGGL(k_bucket_offsets,
                        dim3(ceil_div_u32(plan.max_task_buckets, kOffsetChunkBuckets), num_tasks),
                        dim3(256), 0, stream, b.hist, b.bucket_end, b.chunk_totals, b.tasks);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       sort_lds, stream, b.sorted, b.segment_bucket, b.hist, b.digits, b.tasks);
+    // bucket ranges of <= ~1 MiB of sorted entries each (see k_bucket_scatter)
+    u32 ranges = ceil_div_u32(plan.max_rows * sizeof(u32), ctx.tuning.scatter_range_bytes);
+    if (ranges > 8) ranges = 8; // every range re-reads the slice's digits
+    if (ranges > plan.max_task_buckets) ranges = plan.max_task_buckets;
+    if (ranges < 1) ranges = 1;
+    const u32 units = num_tasks * ranges;
+    const u32 blocks = 8 * plan.max_task_slices * ceil_div_u32(units, 8);
+    const size_t scatter_lds = sizeof(u32) * ceil_div_u32(plan.max_task_buckets, ranges);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(kSortThreads), scatter_lds, stream,
+                       b.sorted, b.segment_bucket, b.hist, b.digits, b.tasks, num_tasks, ranges,
+                       plan.max_task_slices);
   });
   ctx.timer.timed(timing, 3, stream, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,

@@ -202,19 +202,39 @@ static __global__ void __launch_bounds__(256)
 }
 
 // sorted[task.entry_base + pos] = row | (digit negative) << 31, grouped by bucket;
-// segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment
+// segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment.
+//
+// The scatter writes 4 bytes to an essentially random position of the task's sorted list, so its
+// speed is set by how many of those writes merge into full lines before they leave the L2
+// (measured: 0.16 of the 0.22 ms of this kernel at config 2 are the random writes).  Work is
+// therefore cut by *bucket range* as well: a unit = (task, 1/Q of the buckets) owns a contiguous
+// <= ~1 MiB piece of the sorted list, its slices (one workgroup each) re-read the slice's digits
+// and keep only their bucket range, and the block index is laid out so that all slices of a unit
+// -- and only two units at a time -- land on the same XCD (observed placement: block b -> XCD
+// b % 8; used for L2 affinity only, results do not depend on it).
 static __global__ void __launch_bounds__(kSortThreads)
     k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
                      const u32* __restrict__ offsets, const i16* __restrict__ digits,
-                     const task_desc* __restrict__ tasks) {
+                     const task_desc* __restrict__ tasks, u32 num_tasks, u32 ranges_per_task,
+                     u32 slices_per_unit) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  const task_desc task = tasks[blockIdx.y];
-  const u32 slice = blockIdx.x;
+  // block = xcd + 8 * (slice + slices_per_unit * unit_group), unit = 8 * unit_group + xcd
+  const u32 xcd = blockIdx.x & 7;
+  const u32 rest = blockIdx.x >> 3;
+  const u32 slice = rest % slices_per_unit;
+  const u32 unit = (rest / slices_per_unit) * 8 + xcd;
+  if (unit >= num_tasks * ranges_per_task) return;
+  const task_desc task = tasks[unit / ranges_per_task];
   if (slice >= task.num_slices) return;
   const u32 nb = task.num_buckets;
+  const u32 range = unit % ranges_per_task;
+  const u32 per_range = (nb + ranges_per_task - 1) / ranges_per_task;
+  const u32 b_lo = range * per_range;
+  if (b_lo >= nb) return;
+  const u32 b_hi = b_lo + per_range < nb ? b_lo + per_range : nb;
   const u32 tid = threadIdx.x;
-  const u32* in = offsets + task.hist_base + static_cast<u64>(slice) * nb;
-  for (u32 b = tid; b < nb; b += kSortThreads) lds[b] = in[b];
+  const u32* in = offsets + task.hist_base + static_cast<u64>(slice) * nb + b_lo;
+  for (u32 b = tid; b < b_hi - b_lo; b += kSortThreads) lds[b] = in[b];
   __syncthreads();
   const u64 row0 = static_cast<u64>(slice) * kSliceRows;
   const u32 rows = static_cast<u32>(task.rows - row0 < kSliceRows ? task.rows - row0 : kSliceRows);
@@ -222,10 +242,11 @@ static __global__ void __launch_bounds__(kSortThreads)
   u32* seg = segment_bucket + task.segment_base;
   for_each_slice_digit(digits + task.entry_base + row0, rows, [&](u32 r, int e) {
     // E = -D: positive E means the digit is negative -> subtract the generator
-    const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
-    const u32 pos = atomicAdd(&lds[mag - 1], 1u);
+    const u32 bucket = (e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e)) - 1;
+    if (bucket < b_lo || bucket >= b_hi) return;
+    const u32 pos = atomicAdd(&lds[bucket - b_lo], 1u);
     out[pos] = (static_cast<u32>(row0) + r) | (e > 0 ? 0x80000000u : 0u);
-    if (pos % kSegmentEntries == 0) seg[pos / kSegmentEntries] = mag - 1;
+    if (pos % kSegmentEntries == 0) seg[pos / kSegmentEntries] = bucket;
   });
 }
 

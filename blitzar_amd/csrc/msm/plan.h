@@ -82,6 +82,8 @@ struct msm_tuning {
   // window-width cost model: from this many columns on, buckets cost `throughput_bucket_cost`
   size_t throughput_columns = 4;
   double throughput_bucket_cost = 12.0;
+  // k_bucket_scatter: bytes of sorted entries one (task, bucket range) unit covers
+  size_t scatter_range_bytes = size_t{1} << 19;
 };
 
 inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b); }
