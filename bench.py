@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=None, help="override rows (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=16,
+    ap.add_argument("--cpu-log2n", type=int, default=20,
                     help="rows of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -136,6 +136,22 @@ def main():
     stage_ms = (ctypes.c_double * 6)()
     calls = lib.bzamd_stage_timing_collect(stage_ms)
 
+    # informational second leg (rank 0 of a single-GPU run): the same step with the generators
+    # registered once as a resident set (bzamd_generators_*), i.e. without the
+    # per-call conversion of caller generators.  Never used for `value`.
+    resident_ms = None
+    if world == 1:
+        handle = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(generators.data_ptr()), n, sh)
+        for _ in range(args.warmup):
+            lib.bzamd_msm_device_resident(ctypes.c_void_p(out.data_ptr()), 1, desc, handle, sh)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            lib.bzamd_msm_device_resident(ctypes.c_void_p(out.data_ptr()), 1, desc, handle, sh)
+        torch.cuda.synchronize()
+        resident_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        lib.bzamd_generators_free(handle)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,6 +177,8 @@ def main():
             "config": {"workload": name if args.log2n is None else f"curve25519_msm_n2^{log2n}_252bit",
                        "columns_per_gpu": 1, "rows": n, "parallelism": f"columns x{world}"},
         }
+        if resident_ms is not None:
+            result["resident_generators_ms_per_step"] = resident_ms
         if calls > 0:
             per_call = {STAGES[i]: stage_ms[i] / calls for i in range(6)}
             result["stage_ms"] = {k: round(v, 4) for k, v in per_call.items()}

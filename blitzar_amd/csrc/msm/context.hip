@@ -20,13 +20,7 @@ const curve_vtable* curve_vtable_for(unsigned curve_id) {
   }
 }
 
-msm_context* msm_context_new() {
-  msm_context* ctx = new msm_context();
-  if (const char* v = std::getenv("BZAMD_SCATTER_RANGE_BYTES")) {
-    ctx->tuning.scatter_range_bytes = std::strtoull(v, nullptr, 10); // experiment knob
-  }
-  return ctx;
-}
+msm_context* msm_context_new() { return new msm_context(); }
 void msm_context_free(msm_context* ctx) { delete ctx; }
 void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
                             size_t max_workspace_bytes) {

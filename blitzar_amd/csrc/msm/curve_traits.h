@@ -41,10 +41,9 @@ struct ed25519_msm {
   static constexpr size_t projective_size = 160;    // element_p3 (fixed-base results)
   // register budget of k_accumulate: 3 waves per SIMD = at most 168 VGPRs (accumulator, current
   // addend, prefetched next addend, product temporaries)
-#ifndef BZ_ED_ACC_WAVES
-#define BZ_ED_ACC_WAVES 3
-#endif
-  static constexpr int accumulate_waves_per_simd = BZ_ED_ACC_WAVES;
+  // (measured on MI355X at config 2: 2 / 3 / 4 waves per SIMD -> 0.862 / 0.860 / 1.13 ms, the last
+  // one spills: the kernel is issue-bound, not latency-bound)
+  static constexpr int accumulate_waves_per_simd = 3;
 
   BZ_HD static point identity() { return ed29::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return ed29::add(a, b); }

@@ -77,10 +77,6 @@ struct msm_context {
   stage_timer timer;
 };
 
-template <class C> struct msm_workspace_sizes {
-  size_t total = 0;
-};
-
 // one-time kernel attributes: the sort kernels need up to 128 KiB of dynamic LDS
 static void configure_sort_kernels() {
   static bool done = false;
@@ -140,36 +136,42 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   // Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.
   if (any_signed && tune.max_window_bits > 15) tune.max_window_bits = 15;
 
+  // cut the columns into batches: the longest prefix of the remaining columns whose plan respects
+  // the launch-grid and workspace limits (a single column is always accepted); found by bisection,
+  // the usual case -- everything fits -- costs one planning pass
   std::vector<msm_plan> batches;
   std::vector<size_t> first_column;
   size_t need = 0;
+  const bool needs_addends = d_addends == nullptr;
+  auto plan_range = [&](size_t begin, size_t end, size_t& bytes) {
+    msm_plan p = make_msm_plan(std::vector<host_column>(cols.begin() + begin, cols.begin() + end), tune);
+    bytes = msm_workspace_bytes<C>(p, needs_addends, partial_stride_of(p));
+    return p;
+  };
+  auto fits = [&](const msm_plan& p, size_t bytes) {
+    return p.tasks.size() <= tune.max_tasks_per_batch && bytes <= tune.max_workspace_bytes;
+  };
   for (size_t begin = 0; begin < cols.size();) {
-    size_t end = begin;
-    msm_plan plan;
-    // grow the batch column by column (re-planning a prefix is cheap: a few fields per task)
-    while (end < cols.size()) {
-      std::vector<host_column> trial(cols.begin() + begin, cols.begin() + end + 1);
-      msm_plan p = make_msm_plan(trial, tune);
-      const size_t bytes = msm_workspace_bytes<C>(p, d_addends == nullptr, partial_stride_of(p));
-      if (end > begin && (p.tasks.size() > tune.max_tasks_per_batch || bytes > tune.max_workspace_bytes)) {
-        break;
-      }
-      plan = std::move(p);
-      ++end;
-      // jump ahead in large uniform jobs: avoid quadratic re-planning
-      if (end - begin >= 8) {
-        const size_t step = end - begin;
-        while (end + step <= cols.size()) {
-          std::vector<host_column> t2(cols.begin() + begin, cols.begin() + end + step);
-          msm_plan p2 = make_msm_plan(t2, tune);
-          const size_t b2 = msm_workspace_bytes<C>(p2, d_addends == nullptr, partial_stride_of(p2));
-          if (p2.tasks.size() > tune.max_tasks_per_batch || b2 > tune.max_workspace_bytes) break;
-          plan = std::move(p2);
-          end += step;
+    size_t bytes = 0;
+    size_t end = cols.size();
+    msm_plan plan = plan_range(begin, end, bytes);
+    if (!fits(plan, bytes) && end - begin > 1) {
+      size_t lo = begin + 1, hi = end; // [begin, lo) is accepted, [begin, hi) is known not to fit
+      plan = plan_range(begin, lo, bytes);
+      while (hi - lo > 1) {
+        const size_t mid = lo + (hi - lo) / 2;
+        size_t mid_bytes = 0;
+        msm_plan p = plan_range(begin, mid, mid_bytes);
+        if (fits(p, mid_bytes)) {
+          plan = std::move(p);
+          bytes = mid_bytes;
+          lo = mid;
+        } else {
+          hi = mid;
         }
       }
+      end = lo;
     }
-    const size_t bytes = msm_workspace_bytes<C>(plan, d_addends == nullptr, partial_stride_of(plan));
     if (bytes > need) need = bytes;
     first_column.push_back(begin);
     batches.push_back(std::move(plan));
