@@ -88,4 +88,49 @@ private:
   size_t capacity_ = 0;
   size_t used_ = 0;
 };
+
+// Pinned host staging for small per-call descriptor arrays that are uploaded with hipMemcpyAsync:
+// the source must stay valid until the copy has executed, and the planning structures it comes from
+// die when the enqueue function returns.  A ring of pinned slots, each guarded by an event recorded
+// after its copy, keeps calls asynchronous without reading freed or pageable memory later.
+class host_stage_ring {
+public:
+  static constexpr int kSlots = 8;
+  host_stage_ring() = default;
+  host_stage_ring(const host_stage_ring&) = delete;
+  host_stage_ring& operator=(const host_stage_ring&) = delete;
+  ~host_stage_ring() {
+    for (int i = 0; i < kSlots; ++i) {
+      if (ptr_[i] != nullptr) (void)hipHostFree(ptr_[i]);
+      if (event_[i] != nullptr) (void)hipEventDestroy(event_[i]);
+    }
+  }
+  // a pinned buffer of at least `bytes`; blocks only if the slot's previous copy is still pending
+  void* acquire(size_t bytes) {
+    slot_ = (slot_ + 1) % kSlots;
+    if (event_[slot_] == nullptr) {
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&event_[slot_], hipEventDisableTiming));
+    } else if (armed_[slot_]) {
+      BZ_HIP_CHECK(hipEventSynchronize(event_[slot_]));
+    }
+    if (bytes > cap_[slot_]) {
+      if (ptr_[slot_] != nullptr) BZ_HIP_CHECK(hipHostFree(ptr_[slot_]));
+      cap_[slot_] = bytes + bytes / 2 + 256;
+      BZ_HIP_CHECK(hipHostMalloc(&ptr_[slot_], cap_[slot_], hipHostMallocDefault));
+    }
+    return ptr_[slot_];
+  }
+  // call after the copies out of the buffer returned by the last acquire() were enqueued
+  void release(hipStream_t stream) {
+    BZ_HIP_CHECK(hipEventRecord(event_[slot_], stream));
+    armed_[slot_] = true;
+  }
+
+private:
+  void* ptr_[kSlots] = {};
+  size_t cap_[kSlots] = {};
+  hipEvent_t event_[kSlots] = {};
+  bool armed_[kSlots] = {};
+  int slot_ = 0;
+};
 } // namespace bz

@@ -4,6 +4,7 @@
 // reference's).
 #pragma once
 
+#include <cstring>
 #include <vector>
 
 #include "blitzar_amd/csrc/base/device.h"
@@ -73,6 +74,7 @@ struct stage_timer {
 
 struct msm_context {
   device_arena arena;
+  host_stage_ring descriptors; // pinned copies of the column / task descriptors in flight
   msm_tuning tuning;
   stage_timer timer;
 };
@@ -216,8 +218,17 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.partial_stride = partial_stride_of(plan);
   b.cols = ctx.arena.take<column_desc>(num_cols);
   b.tasks = ctx.arena.take<task_desc>(num_tasks + 1);
-  BZ_HIP_CHECK(hipMemcpyAsync(b.cols, plan.columns.data(), sizeof(column_desc) * num_cols,
-                              hipMemcpyHostToDevice, stream));
+  // descriptors go through pinned staging: `plan` does not outlive this call, the copies do
+  const size_t col_bytes = sizeof(column_desc) * num_cols, task_bytes = sizeof(task_desc) * num_tasks;
+  char* staged = static_cast<char*>(ctx.descriptors.acquire(col_bytes + task_bytes));
+  std::memcpy(staged, plan.columns.data(), col_bytes);
+  if (task_bytes != 0) std::memcpy(staged + col_bytes, plan.tasks.data(), task_bytes);
+  BZ_HIP_CHECK(hipMemcpyAsync(b.cols, staged, col_bytes, hipMemcpyHostToDevice, stream));
+  if (task_bytes != 0) {
+    BZ_HIP_CHECK(hipMemcpyAsync(b.tasks, staged + col_bytes, task_bytes, hipMemcpyHostToDevice,
+                                stream));
+  }
+  ctx.descriptors.release(stream);
   if (num_tasks == 0) {
     // every column is empty: identities only
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
@@ -227,8 +238,6 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     BZ_HIP_CHECK(hipGetLastError());
     return;
   }
-  BZ_HIP_CHECK(hipMemcpyAsync(b.tasks, plan.tasks.data(), sizeof(task_desc) * num_tasks,
-                              hipMemcpyHostToDevice, stream));
   const bool timing = ctx.timer.recording();
   if (d_addends == nullptr) {
     addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
