@@ -107,6 +107,7 @@ checked_columns check_descriptors(const sxt_sequence_descriptor* descriptors, u3
                       "element_nbytes must be in [1, 32]");
     BZ_RELEASE_ASSERT(!d.is_signed || d.element_nbytes <= 16,
                       "signed sequences need element_nbytes <= 16");
+    BZ_RELEASE_ASSERT(d.n < (uint64_t{1} << 31), "sequences are limited to 2^31 - 1 rows");
     r.cols[i] = byte_column(d.data, d.n, d.element_nbytes, d.is_signed != 0);
     r.longest = std::max<u64>(r.longest, d.n);
     r.total_bytes += device_arena::padded(static_cast<size_t>(d.n) * d.element_nbytes + 32);

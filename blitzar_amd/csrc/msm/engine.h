@@ -151,7 +151,9 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     return p;
   };
   auto fits = [&](const msm_plan& p, size_t bytes) {
-    return p.tasks.size() <= tune.max_tasks_per_batch && bytes <= tune.max_workspace_bytes;
+    // tasks and columns are launch-grid dimensions (grid.y <= 65535)
+    return p.tasks.size() <= tune.max_tasks_per_batch && p.columns.size() <= 32768 &&
+           bytes <= tune.max_workspace_bytes;
   };
   for (size_t begin = 0; begin < cols.size();) {
     size_t bytes = 0;
@@ -233,7 +235,9 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     // every column is empty: identities only
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
                        out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
-                       static_cast<const point*>(nullptr), 1u, b.cols, 0u, 0u, 1, 1);
+                       static_cast<const point*>(nullptr), 1u, b.cols,
+                       static_cast<const task_desc*>(nullptr), static_cast<const u32*>(nullptr), 0u,
+                       0u, 1, 1);
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipGetLastError());
     return;
@@ -303,7 +307,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   ctx.timer.timed(timing, 5, stream, [&] {
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
-                       b.partial_stride, b.cols, 0u, 0xffffffffu, 1, 1);
+                       b.partial_stride, b.cols, b.tasks, b.bucket_end, 0u, 0xffffffffu, 1, 1);
   });
   if (timing) ctx.timer.calls += 1;
   g_kernel_launches += 7;

@@ -254,6 +254,9 @@ def test_skewed_and_batched_columns(gpu_backend, oracle):
     cols = [(np.tile(one, (n, 1)), False), (two[rng.integers(0, 2, n)], False),
             (np.full((n, 32), 0xff, np.uint8), False), (sparse, False),
             (np.ones((n, 1), np.uint8), False), (rng.integers(0, 2, (n, 1), dtype=np.uint8), False)]
+    small = np.zeros((n, 32), np.uint8)           # 40-bit values in 32-byte scalars: the top
+    small[:, :5] = rng.integers(0, 256, (n, 5))    # windows are empty and the chain skips them
+    cols.append((small, False))
     cols += [(rng.integers(0, 256, (n - 7 * k, 1 + (5 * k) % 32), dtype=np.uint8), False)
              for k in range(30)]
     want = oracle.commit(0, cols, gens)
