@@ -41,13 +41,13 @@ void init_host_generators(api_state& st, u64 n) {
     // derive on the device (reference K15), keep both the raw p3 copy (served by
     // sxt_ristretto255_get_generators) and the resident addends
     BZ_RELEASE_ASSERT(curve25519_vtable().addend_size == sizeof(ed29_cached),
-                      "built-in generator cache and MSM engine disagree on the addend layout");
+                      "built-in generator derivation and MSM engine disagree on the addend layout");
     ed_point* d_raw = nullptr;
     BZ_HIP_CHECK(hipMalloc(&d_raw, sizeof(ed_point) * n));
-    BZ_HIP_CHECK(hipMalloc(&st.d_builtin_addends, sizeof(ed29_cached) * n));
+    BZ_HIP_CHECK(hipMalloc(&st.d_builtin_addends, curve25519_vtable().resident_addend_size * n));
     builtin_generators_enqueue(d_raw, 0, n, st.stream);
     g_kernel_launches += 1;
-    curve25519_vtable().prepare_addends(st.d_builtin_addends, d_raw, n, st.stream);
+    curve25519_vtable().prepare_resident(st.d_builtin_addends, d_raw, n, st.stream);
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipMemcpyAsync(st.host_generators.data(), d_raw, sizeof(ed_point) * n,
                                 hipMemcpyDeviceToHost, st.stream));
@@ -160,6 +160,7 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
   }
   const void* d_addends = nullptr;
   const void* d_api_generators = nullptr;
+  bool resident = false;
   if (source == generator_source::host_api) {
     u8* d = st.io.take<u8>(vt.api_generator_size * cc.longest + 32);
     if (cc.longest > 0) {
@@ -169,7 +170,9 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
     d_api_generators = d;
   } else if (offset_generators + cc.longest <= st.host_generators.size() &&
              st.d_builtin_addends != nullptr) {
-    d_addends = st.d_builtin_addends + offset_generators;
+    d_addends = static_cast<const char*>(st.d_builtin_addends) +
+                vt.resident_addend_size * offset_generators;
+    resident = true;
   } else {
     ed29_cached* d = st.io.take<ed29_cached>(cc.longest + 1);
     builtin_addends_enqueue(d, offset_generators, cc.longest, st.stream);
@@ -177,8 +180,12 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
     d_addends = d;
   }
   u8* d_out = st.io.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
-  vt.msm(*st.ctx, d_out, out_stride, projective_out, cc.cols, d_addends, d_api_generators,
-         st.stream);
+  if (resident) {
+    vt.msm_resident(*st.ctx, d_out, out_stride, projective_out, cc.cols, d_addends, st.stream);
+  } else {
+    vt.msm(*st.ctx, d_out, out_stride, projective_out, cc.cols, d_addends, d_api_generators,
+           st.stream);
+  }
   BZ_HIP_CHECK(hipMemcpyAsync(commitments, d_out, static_cast<size_t>(out_stride) * num_sequences,
                               hipMemcpyDeviceToHost, st.stream));
   BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
@@ -330,10 +337,10 @@ void handle_make_resident(multiexp_handle& h) {
   void* d_proj = nullptr;
   const size_t bytes = h.vt->projective_size * h.n;
   BZ_HIP_CHECK(hipMalloc(&d_proj, bytes));
-  BZ_HIP_CHECK(hipMalloc(&h.d_addends, h.vt->addend_size * (h.n + 1)));
+  BZ_HIP_CHECK(hipMalloc(&h.d_addends, h.vt->resident_addend_size * (h.n + 1)));
   BZ_HIP_CHECK(hipMemcpyAsync(d_proj, h.host_projective.data(), bytes, hipMemcpyHostToDevice,
                               st.stream));
-  h.vt->prepare_addends_projective(h.d_addends, d_proj, h.n, st.stream);
+  h.vt->prepare_resident_projective(h.d_addends, d_proj, h.n, st.stream);
   g_kernel_launches += 1;
   BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
   BZ_HIP_CHECK(hipFree(d_proj));
@@ -399,8 +406,8 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
     return;
   }
   if (device_operands) {
-    h.vt->msm(*st.context_for_current_device(), static_cast<u8*>(res), out_stride, true, cols,
-              h.d_addends, nullptr, caller_stream);
+    h.vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(res), out_stride, true,
+                       cols, h.d_addends, caller_stream);
     return;
   }
   st.activate();
@@ -415,7 +422,7 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   }
   for (auto& c : cols) c.data = d_scalars + (c.data - scalars);
   u8* d_out = st.io.take<u8>(out_bytes);
-  h.vt->msm(*st.ctx, d_out, out_stride, true, cols, h.d_addends, nullptr, st.stream);
+  h.vt->msm_resident(*st.ctx, d_out, out_stride, true, cols, h.d_addends, st.stream);
   BZ_HIP_CHECK(hipMemcpyAsync(res, d_out, out_bytes, hipMemcpyDeviceToHost, st.stream));
   BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
   record_result();
@@ -654,8 +661,8 @@ struct bzamd_generators* bzamd_generators_new_device(unsigned curve_id, const vo
   auto g = std::make_unique<resident_generators>();
   g->vt = vt;
   g->n = n;
-  BZ_HIP_CHECK(hipMalloc(&g->d_addends, vt->addend_size * (n + 1)));
-  vt->prepare_addends(g->d_addends, generators, n, static_cast<hipStream_t>(stream));
+  BZ_HIP_CHECK(hipMalloc(&g->d_addends, vt->resident_addend_size * (n + 1)));
+  vt->prepare_resident(g->d_addends, generators, n, static_cast<hipStream_t>(stream));
   g_kernel_launches += 1;
   BZ_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return reinterpret_cast<bzamd_generators*>(g.release());
@@ -692,9 +699,9 @@ void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   BZ_RELEASE_ASSERT(cc.longest <= g->n, "sequence longer than the resident generator set");
-  g->vt->msm(*st.context_for_current_device(), static_cast<u8*>(commitments),
-             static_cast<u32>(g->vt->output_size), false, cc.cols, g->d_addends, nullptr,
-             static_cast<hipStream_t>(stream));
+  g->vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(commitments),
+                      static_cast<u32>(g->vt->output_size), false, cc.cols, g->d_addends,
+                      static_cast<hipStream_t>(stream));
 }
 
 void bzamd_generator_multiples_device(unsigned curve_id, void* generators, const void* base,

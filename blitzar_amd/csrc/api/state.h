@@ -23,7 +23,7 @@ struct api_state {
   // built-in ristretto generators 0 .. num_precomputed-1
   std::vector<ed_point> host_generators;  // raw extended coordinates
   std::vector<ed_point> host_one_commits; // [i] = g_0 + ... + g_{i-1}
-  ed29_cached* d_builtin_addends = nullptr; // resident addends of the same generators
+  void* d_builtin_addends = nullptr;       // resident addends of the same generators (vt layout)
 
   // engine contexts of other devices touched through the device entry points
   std::map<int, msm_context*> device_contexts;

@@ -21,6 +21,16 @@ struct ed29_cached {
   fe29 YpX, YmX, Z, T2d;
 };
 
+// resident addend of a generator set that is registered once and reused (built-in generators,
+// bzamd_generators, sxt_multiexp_handle): normalised to Z = 1, (y+x, y-x, 2dxy), padded to one
+// 128-byte line.  One field product and 80 bytes of gather traffic less per addition than
+// ed29_cached; the normalisation costs an inversion per generator, once.
+struct alignas(16) ed29_niels {
+  fe29 YpX, YmX, T2d;
+  u32 pad[5];
+};
+static_assert(sizeof(ed29_niels) == 128);
+
 namespace ed29 {
 BZ_HD ed29_point identity() { return {f29::zero(), f29::one(), f29::one(), f29::zero()}; }
 
@@ -71,6 +81,39 @@ BZ_HD ed29_point add_cached(const ed29_point& p, const ed29_cached& q, bool nega
 
 BZ_HD ed29_point add(const ed29_point& p, const ed29_point& q) {
   return add_cached(p, to_cached(q), false);
+}
+
+BZ_HD ed29_niels to_niels(const ed29_point& p) {
+  const fe29 zinv = f29::invert(p.Z);
+  const fe29 x = f29::mul(p.X, zinv);
+  const fe29 y = f29::mul(p.Y, zinv);
+  ed29_niels n;
+  n.YpX = f29::weak_reduce(f29::add(y, x));
+  n.YmX = f29::weak_reduce(f29::sub(y, x));
+  n.T2d = f29::mul(f29::mul(x, y), f29::const_2d());
+  for (int i = 0; i < 5; ++i) n.pad[i] = 0;
+  return n;
+}
+
+// p + q (q negated when `negate`) for a Z = 1 addend: 7 field products
+BZ_HD ed29_point add_niels(const ed29_point& p, const ed29_niels& q, bool negate) {
+  const fe29 qa = f29::select(q.YpX, q.YmX, negate);
+  const fe29 qb = f29::select(q.YmX, q.YpX, negate);
+  const fe29 qt = f29::select(q.T2d, f29::neg(q.T2d), negate); // B 2
+  const fe29 a = f29::mul(f29::add(p.Y, p.X), qa);             // 2 * 1
+  const fe29 b = f29::mul(f29::sub(p.Y, p.X), qb);             // 3 * 1
+  const fe29 c = f29::mul(p.T, qt);                            // 1 * 2
+  const fe29 d = f29::add(p.Z, p.Z);                           // B 2
+  const fe29 ez = f29::add(d, c);                              // B 3
+  const fe29 et = f29::weak_reduce(f29::sub(d, c));            // B 4 -> 1
+  const fe29 ex = f29::sub(a, b);                              // B 3
+  const fe29 ey = f29::add(a, b);                              // B 2
+  ed29_point r;
+  r.X = f29::mul(ex, et);
+  r.Y = f29::mul(ey, ez);
+  r.Z = f29::mul(ez, et);
+  r.T = f29::mul(ex, ey);
+  return r;
 }
 
 // 2p; T is only produced when `want_t` (intermediate doublings of a 2^k chain do not need it)

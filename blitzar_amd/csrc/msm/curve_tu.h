@@ -51,7 +51,29 @@ __global__ void __launch_bounds__(64)
   C::store_api_generator(out + i * C::api_generator_size, acc);
 }
 
-template <class C> struct curve_tu {
+// R = the trait used against resident generator sets (C itself, except curve25519's Z = 1 form)
+template <class C, class R = C> struct curve_tu {
+  static void msm_resident(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                           const std::vector<host_column>& cols, const void* d_addends,
+                           hipStream_t stream) {
+    msm_enqueue<R>(ctx, d_out, out_stride, projective_out, cols,
+                   static_cast<const typename R::addend*>(d_addends), nullptr, stream);
+  }
+  static void prepare_resident(void* d_addends, const void* d_api_generators, u64 n,
+                               hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL((k_prepare_addends<R>), dim3(ceil_div_u32(n, 256)), dim3(256), 0, stream,
+                       static_cast<typename R::addend*>(d_addends), d_api_generators, n);
+    BZ_HIP_CHECK(hipGetLastError());
+  }
+  static void prepare_resident_projective(void* d_addends, const void* d_projective, u64 n,
+                                          hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL((k_prepare_addends_projective<R>), dim3(ceil_div_u32(n, 256)), dim3(256), 0,
+                       stream, static_cast<typename R::addend*>(d_addends),
+                       static_cast<const typename R::api_projective*>(d_projective), n);
+    BZ_HIP_CHECK(hipGetLastError());
+  }
   static void msm(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                   const std::vector<host_column>& cols, const void* d_addends,
                   const void* d_api_generators, hipStream_t stream) {
@@ -122,6 +144,10 @@ template <class C> struct curve_tu {
                                  &curve_tu::fold_encode_host,
                                  &curve_tu::fold_encode_device,
                                  &curve_tu::generator_multiples,
+                                 sizeof(typename R::addend),
+                                 &curve_tu::msm_resident,
+                                 &curve_tu::prepare_resident,
+                                 &curve_tu::prepare_resident_projective,
                                  sizeof(typename compact_ops<C>::compact),
                                  &write_partition_table<C>,
                                  &read_partition_generators<C>,

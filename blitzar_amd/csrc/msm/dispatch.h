@@ -38,6 +38,16 @@ struct curve_vtable {
                              hipStream_t stream);
   // d_out[i] = (i + 1) * base, C-ABI generator layout (synthetic generator sets)
   void (*generator_multiples)(void* d_out, const void* d_base_api, u64 n, hipStream_t stream);
+  // resident generator sets (registered once, reused by many calls): their own addend layout
+  // (curve25519: Z = 1, 128 bytes; the Weierstrass curves: the same affine addends)
+  size_t resident_addend_size;
+  void (*msm_resident)(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                       const std::vector<host_column>& cols, const void* d_addends,
+                       hipStream_t stream);
+  void (*prepare_resident)(void* d_addends, const void* d_api_generators, u64 n,
+                           hipStream_t stream);
+  void (*prepare_resident_projective)(void* d_addends, const void* d_projective, u64 n,
+                                      hipStream_t stream);
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
   void (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);

@@ -2,5 +2,5 @@
 #include "blitzar_amd/csrc/msm/curve_tu.h"
 
 namespace bz {
-const curve_vtable& curve25519_vtable() { return curve_tu<ed25519_msm>::vtable(); }
+const curve_vtable& curve25519_vtable() { return curve_tu<ed25519_msm, ed25519_niels_msm>::vtable(); }
 } // namespace bz

@@ -191,11 +191,12 @@ def ed29_dbl_n(a, k):
     return out
 
 
-def ed29_chain(points, negate):
+def ed29_chain(points, negate, niels=False):
     out = np.zeros(20, np.uint64)
     pts = _c(points)
     neg = _c(negate, np.int32)
-    lib().bz_ed29_chain(_p(out), _p(pts), _p(neg), ctypes.c_int(pts.shape[0]))
+    fn = lib().bz_ed29_chain_niels if niels else lib().bz_ed29_chain
+    fn(_p(out), _p(pts), _p(neg), ctypes.c_int(pts.shape[0]))
     return out
 
 

@@ -242,6 +242,17 @@ void bz_ed29_dbl_n(u64* out, const u64* a, int k) {
   ed_point e = ed29::to_ed(ed29::dbl_n(ed29::from_ed(p), k));
   std::memcpy(out, &e, 160);
 }
+// the same chain through the Z = 1 resident addends (ed29_niels, 7-product addition)
+void bz_ed29_chain_niels(u64* out, const u64* points, const int* negate, int n) {
+  ed29_point acc = ed29::identity();
+  for (int i = 0; i < n; ++i) {
+    ed_point q;
+    std::memcpy(&q, points + 20 * i, 160);
+    acc = ed29::add_niels(acc, ed29::to_niels(ed29::from_ed(q)), negate[i] != 0);
+  }
+  ed_point e = ed29::to_ed(acc);
+  std::memcpy(out, &e, 160);
+}
 // long chain: acc = sum_i (+-) q_i, stressing the limb bounds of repeated accumulation
 void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
   ed29_point acc = ed29::identity();

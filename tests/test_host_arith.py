@@ -253,6 +253,11 @@ def test_ed29_group_law_matches_reference(oracle):
     for q, s in zip(g, signs):
         acc = hooks.ed_sub(acc, q) if s else oracle.add_projective(0, acc, q)
     assert np.array_equal(canon(hooks.ed29_chain(g, signs)), canon(acc))
+    assert np.array_equal(canon(hooks.ed29_chain(g, signs, niels=True)), canon(acc))
+    # doubling and cancellation through the Z = 1 addends (unified formulas)
+    twice = np.stack([g[0], g[0], g[1], g[1]])
+    assert np.array_equal(canon(hooks.ed29_chain(twice, [0, 0, 0, 1], niels=True)),
+                          canon(oracle.double_projective(0, g[0])))
 
 
 #--------------------------------------------------------------------------------------------------
