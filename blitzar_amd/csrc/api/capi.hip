@@ -40,7 +40,7 @@ void init_host_generators(api_state& st, u64 n) {
   if (st.backend == SXT_GPU_BACKEND) {
     // derive on the device (reference K15), keep both the raw p3 copy (served by
     // sxt_ristretto255_get_generators) and the resident addends
-    BZ_RELEASE_ASSERT(curve25519_vtable().addend_size == sizeof(ed29_cached),
+    BZ_RELEASE_ASSERT(curve25519_vtable().addend_size == sizeof(ed29_cached_packed),
                       "built-in generator derivation and MSM engine disagree on the addend layout");
     ed_point* d_raw = nullptr;
     BZ_HIP_CHECK(hipMalloc(&d_raw, sizeof(ed_point) * n));
@@ -174,7 +174,7 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
                 vt.resident_addend_size * offset_generators;
     resident = true;
   } else {
-    ed29_cached* d = st.io.take<ed29_cached>(cc.longest + 1);
+    ed29_cached_packed* d = st.io.take<ed29_cached_packed>(cc.longest + 1);
     builtin_addends_enqueue(d, offset_generators, cc.longest, st.stream);
     g_kernel_launches += 1;
     d_addends = d;

@@ -31,7 +31,37 @@ struct alignas(16) ed29_niels {
 };
 static_assert(sizeof(ed29_niels) == 128);
 
+// ed29_cached as it sits in HBM: the four coordinates as canonical 256-bit little-endian integers,
+// 128 bytes = exactly one line per gather (144 bytes of limbs straddle 3-4 sectors of 64 bytes;
+// measured: the aligned form is worth more than the ~70 VALU instructions that unpack it)
+struct alignas(16) ed29_cached_packed {
+  u32 w[32];
+};
+static_assert(sizeof(ed29_cached_packed) == 128);
+
 namespace ed29 {
+BZ_HD void pack_words(u32* w, const fe29& f) {
+  u64 q[4];
+  f29::to_words(q, f);
+  for (int i = 0; i < 4; ++i) {
+    w[2 * i] = static_cast<u32>(q[i]);
+    w[2 * i + 1] = static_cast<u32>(q[i] >> 32);
+  }
+}
+
+// eight 32-bit words of a value < 2^256 -> nine 29-bit limbs (all below 2^29)
+BZ_HD fe29 unpack_words(const u32* w) {
+  fe29 h;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int bit = 29 * i, j = bit >> 5, sh = bit & 31;
+    u32 v = w[j] >> sh;
+    if (sh > 3 && j + 1 < 8) v |= w[j + 1] << (32 - sh);
+    h.v[i] = v & f29::kMask;
+  }
+  return h;
+}
+
 BZ_HD ed29_point identity() { return {f29::zero(), f29::one(), f29::one(), f29::zero()}; }
 
 BZ_HD ed29_point from_ed(const ed_point& p) {
@@ -52,6 +82,19 @@ BZ_HD ed29_cached to_cached(const ed29_point& p) {
 }
 
 BZ_HD ed29_cached cached_from_ed(const ed_point& p) { return to_cached(from_ed(p)); }
+
+BZ_HD ed29_cached_packed pack(const ed29_cached& c) {
+  ed29_cached_packed m;
+  pack_words(m.w, c.YpX);
+  pack_words(m.w + 8, c.YmX);
+  pack_words(m.w + 16, c.Z);
+  pack_words(m.w + 24, c.T2d);
+  return m;
+}
+
+BZ_HD ed29_cached unpack(const ed29_cached_packed& m) {
+  return {unpack_words(m.w), unpack_words(m.w + 8), unpack_words(m.w + 16), unpack_words(m.w + 24)};
+}
 
 // p + q, or p - q when `negate` (one code path: the sign only selects operands, so lanes of a
 // wavefront with different digit signs do not diverge)

@@ -26,6 +26,13 @@ template <int N> struct sw29_affine {
   fe29m<N> x, y;
 };
 
+// the addend as it sits in HBM: both coordinates as canonical integers of the mont29 form, packed
+// into 64-bit words -- 64 bytes (bn254, grumpkin: one sector per gather instead of 72 bytes
+// straddling two or three) or 96 bytes (bls12-381).  (0, 0) marks the identity.
+template <int N64> struct sw29_affine_packed {
+  u64 x[N64], y[N64];
+};
+
 // P: field F (mont29<...>), the ABI-form curve G64 (sw<...>), |3b| and its sign
 template <class P> struct sw29 {
   using F = typename P::F;
@@ -192,6 +199,21 @@ template <class P> struct sw29 {
       a.y = F::zero();
     }
     return a;
+  }
+
+  using packed = sw29_affine_packed<N64>;
+  BZ_HD static packed pack(const affine& a) {
+    packed m;
+    F::to_words(m.x, F::canonical(F::norm(a.x)));
+    F::to_words(m.y, F::canonical(F::norm(a.y)));
+    return m;
+  }
+  BZ_HD static affine unpack(const packed& m) { return {F::from_words(m.x), F::from_words(m.y)}; }
+  BZ_HD static bool is_identity_addend(const packed& m) {
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < N64; ++i) acc |= m.x[i] | m.y[i];
+    return acc == 0;
   }
 
   // exact test on stored addends (the identity is written as all-zero limbs)

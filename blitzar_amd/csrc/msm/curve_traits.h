@@ -31,7 +31,7 @@ static_assert(sizeof(sw_api_affine<6>) == 104);
 struct ed25519_msm {
   static constexpr unsigned curve_id = 0;
   using point = ed29_point;
-  using addend = ed29_cached;
+  using addend = ed29_cached_packed; // (Y+X, Y-X, Z, 2dT), 4 x 256 bits
   using api_projective = ed_point; // sxt_ristretto255 / c21t::element_p3
   // Itanium-mangled names of the reference types (meta.txt of a BLITZAR_DUMP_DIR recording)
   static constexpr const char* reference_element_name = "N3sxt4c21t10element_p3E";
@@ -50,14 +50,14 @@ struct ed25519_msm {
   BZ_HD static point dbl_n(const point& a, int k) { return ed29::dbl_n(a, k); }
   BZ_HD static point neg(const point& a) { return ed29::neg(a); }
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
-    acc = ed29::add_cached(acc, q, negate);
+    acc = ed29::add_cached(acc, ed29::unpack(q), negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
-    return ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]);
+    return ed29::pack(ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]));
   }
   // handle generators arrive as element_p3 too
   BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {
-    return ed29::cached_from_ed(static_cast<const ed_point*>(projective)[i]);
+    return make_addend(projective, i);
   }
   BZ_HD static void encode(u8* out, const point& p) { ristretto29::encode(out, p); }
   BZ_HD static void store_projective(u8* out, const point& p) {
@@ -115,7 +115,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   using F64 = typename G64::F;
   static constexpr int N64 = F64::N;
   using point = typename G29::point;
-  using addend = typename G29::affine; // (0, 0) marks the identity (never on y^2 = x^3 + b, b != 0)
+  using addend = typename G29::packed; // affine (x, y); (0, 0) marks the identity (never on the curve)
   using api_projective = typename G64::point; // sxt_*_p2 / element_p2
   using api_affine = sw_api_affine<N64>;
   static constexpr size_t api_generator_size = sizeof(api_affine);
@@ -128,17 +128,17 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   BZ_HD static point dbl_n(const point& a, int k) { return G29::dbl_n(a, k); }
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     if (G29::is_identity_addend(q)) return;
-    acc = G29::add_mixed(acc, q, negate);
+    acc = G29::add_mixed(acc, G29::unpack(q), negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];
-    return G29::affine_from_mont64(g.X, g.Y, g.infinity != 0);
+    return G29::pack(G29::affine_from_mont64(g.X, g.Y, g.infinity != 0));
   }
   // handle generators: ABI projective element -> affine (one inversion, ABI-form arithmetic)
   BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {
     typename G64::affine a;
     const bool inf = G64::to_affine(a, static_cast<const api_projective*>(projective)[i]);
-    return G29::affine_from_mont64(a.x.v, a.y.v, inf);
+    return G29::pack(G29::affine_from_mont64(a.x.v, a.y.v, inf));
   }
   BZ_HD static point point_from_api_projective(const void* projective, u64 i) {
     return G29::from_point64(static_cast<const api_projective*>(projective)[i]);
