@@ -69,10 +69,13 @@ def main():
                 valu_busy = 4 * act / (1024 * cyc)
             out = {"kernel": acc[0], "fetch_kib": f, "write_kib": w, "valu_busy": valu_busy,
                    "k_accumulate_bytes_per_launch": (f + w) * 1024,
-                   "note": "FETCH_SIZE + WRITE_SIZE (KiB) x 1024, separate --pmc passes; the "
-                           "gathers are per-lane 16-byte loads of random 144-byte rows, for which "
-                           "FETCH_SIZE matches the 64-byte-sector count of the rows (no x2 "
-                           "streaming correction applies), see DESIGN.md"}
+                   "note": "FETCH_SIZE + WRITE_SIZE (KiB) x 1024, separate --pmc passes, raw "
+                           "counter values.  The gathers are per-lane 16-byte loads of random "
+                           "128-byte aligned rows; FETCH_SIZE tallies a 128-byte request as 64 "
+                           "bytes on gfx950 (MI355X_MICROARCH.md, HBM), so the read side may be up "
+                           "to 2x this figure: 17.8 M rows x 128 B = 2.3 GB is the expected gather "
+                           "volume, most of it served by the 256 MiB Infinity Cache, which the "
+                           "counter does not exclude"}
             if len(sys.argv) > 2:
                 with open(sys.argv[2], "w") as fh:
                     json.dump(out, fh, indent=1)
