@@ -17,6 +17,7 @@ struct api_state {
   int backend = 0; // SXT_CPU_BACKEND / SXT_GPU_BACKEND
   int device = 0;  // device current at sxt_init; the blocking sxt_* calls run there
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr; // H2D of the next chunk of columns beside the computation
   msm_context* ctx = nullptr;
   device_arena io; // staging of host operands / results of the blocking sxt_* calls
 
@@ -47,6 +48,7 @@ struct api_state {
       if (d_builtin_addends != nullptr) (void)hipFree(d_builtin_addends);
       if (ctx != nullptr) msm_context_free(ctx);
       for (auto& kv : device_contexts) msm_context_free(kv.second);
+      if (copy_stream != nullptr) (void)hipStreamDestroy(copy_stream);
       if (stream != nullptr) (void)hipStreamDestroy(stream);
     }
   }
