@@ -18,9 +18,13 @@ namespace bz {
 namespace ed29 {
 
 // value of lane K of the caller's quad (lanes 4q .. 4q+3)
+// (the empty asm keeps the move a plain v_mov_b32_dpp: hipcc's fold of a DPP move into
+// v_subrev_u32_dpp was observed to miscompute, see curve/sw29_coop.h)
 template <int K> __device__ __forceinline__ u32 quad_get(u32 v) {
-  return static_cast<u32>(
+  u32 r = static_cast<u32>(
       __builtin_amdgcn_update_dpp(0, static_cast<int>(v), K * 0x55, 0xf, 0xf, true));
+  asm volatile("" : "+v"(r));
+  return r;
 }
 
 template <int K> __device__ __forceinline__ fe29 quad_get(const fe29& f) {

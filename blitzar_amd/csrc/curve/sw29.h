@@ -42,6 +42,7 @@ template <class P> struct sw29 {
   static constexpr int N64 = F::N64;
   using point = sw29_point<N>;
   using affine = sw29_affine<N>;
+  static constexpr bool b3_negative = P::b3_negative;
 
   BZ_HD static point identity() { return {F::zero(), F::one(), F::zero()}; }
 

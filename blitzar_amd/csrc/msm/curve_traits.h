@@ -10,6 +10,7 @@
 #include "blitzar_amd/csrc/curve/ed29.h"
 #include "blitzar_amd/csrc/curve/ed29_coop.h"
 #include "blitzar_amd/csrc/curve/sw29.h"
+#include "blitzar_amd/csrc/curve/sw29_coop.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
 
 namespace bz {
@@ -121,7 +122,25 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr size_t api_generator_size = sizeof(api_affine);
   static constexpr size_t projective_size = sizeof(api_projective);
   static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
-  static constexpr bool has_wave_horner = false;
+  // k_horner's dependent chain on one wavefront: doublings split over the lanes of each DPP quad
+  // (curve/sw29_coop.h), the one addition per window computed redundantly by every lane
+  static constexpr bool has_wave_horner = true;
+#if defined(__HIPCC__)
+  __device__ static point wave_horner(point acc, bool have_acc, const point* window_sums,
+                                      u32 stride, u32 num_windows, u32 window_bits) {
+    const u32 role = threadIdx.x & 3;
+    u32 i = num_windows;
+    if (!have_acc) {
+      acc = window_sums[(num_windows - 1) * stride];
+      i = num_windows - 1;
+    }
+    while (i-- > 0) {
+      for (u32 k = 0; k < window_bits; ++k) acc = sw29_coop::dbl_coop4<G29>(acc, role);
+      acc = G29::add(acc, window_sums[i * stride]);
+    }
+    return acc;
+  }
+#endif
 
   BZ_HD static point identity() { return G29::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return G29::add(a, b); }
