@@ -269,7 +269,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // One stream, stages in order.  (Running the sort of window group k+1 and the reduce / Horner of
   // group k-1 on side streams under the accumulation of group k was measured on MI355X and is
   // slower, 1.94 -> 2.0-2.3 ms at config 2: k_accumulate's waves hold 480 of a SIMD's 512 VGPRs,
-  // so side kernels only get slots as accumulate waves retire and both sides lose.)
+  // so side kernels only get slots as accumulate waves retire and both sides lose.  A second
+  // attempt -- two window groups, the high group's reduce + Horner on a highest-priority stream
+  // beside the low group's accumulation, that launch held to two workgroups per CU with unused
+  // dynamic LDS so registers stay free -- still queued the side kernels behind the accumulation:
+  // 1.74 -> 1.87 ms.)
   ctx.timer.timed(timing, 1, stream, [&] {
     hipLaunchKernelGGL(k_recode, dim3(ceil_div_u32(plan.max_rows, 256), num_cols), dim3(256), 0,
                        stream, b.digits, b.cols, b.tasks);
