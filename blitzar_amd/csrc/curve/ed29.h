@@ -193,11 +193,14 @@ BZ_HD ed29_point neg(const ed29_point& p) {
 // ristretto::encode_words in curve/ed25519.h, reference sxt/ristretto/base/byte_conversion.cc:
 // 74-129); the output bytes are canonical, hence identical.
 namespace ristretto29 {
-BZ_HD bool sqrt_ratio_m1(fe29& x, const fe29& u, const fe29& v) {
+// `pow22523`: z -> z^((p - 5) / 8); a parameter so that k_horner can run the 252 dependent
+// squarings lane-parallel (curve/ed16_wave.h)
+template <class Pow>
+BZ_HD bool sqrt_ratio_m1(fe29& x, const fe29& u, const fe29& v, Pow&& pow22523) {
   const fe29 sqrtm1 = f29::const_sqrtm1();
   const fe29 v3 = f29::mul(f29::sq(v), v);
   x = f29::mul(f29::mul(f29::sq(v3), u), v);
-  x = f29::pow22523(x);
+  x = pow22523(x);
   x = f29::mul(f29::mul(x, v3), u);
   const fe29 vxx = f29::mul(f29::sq(x), v);
   const fe29 m_root_check = f29::sub(vxx, u);
@@ -212,13 +215,17 @@ BZ_HD bool sqrt_ratio_m1(fe29& x, const fe29& u, const fe29& v) {
   return has_m_root | has_p_root;
 }
 
-BZ_HD void encode_words(u64 out[4], const ed29_point& p) {
+BZ_HD bool sqrt_ratio_m1(fe29& x, const fe29& u, const fe29& v) {
+  return sqrt_ratio_m1(x, u, v, [](const fe29& z) { return f29::pow22523(z); });
+}
+
+template <class Pow> BZ_HD void encode_words(u64 out[4], const ed29_point& p, Pow&& pow22523) {
   const fe29 one = f29::one();
   const fe29 u1 = f29::mul(f29::add(p.Z, p.Y), f29::sub(p.Z, p.Y)); // 2 * 3
   const fe29 u2 = f29::mul(p.X, p.Y);
   const fe29 u1_u2u2 = f29::mul(u1, f29::sq(u2));
   fe29 inv_sqrt;
-  (void)sqrt_ratio_m1(inv_sqrt, one, u1_u2u2);
+  (void)sqrt_ratio_m1(inv_sqrt, one, u1_u2u2, pow22523);
   const fe29 den1 = f29::mul(inv_sqrt, u1);
   const fe29 den2 = f29::mul(inv_sqrt, u2);
   const fe29 z_inv = f29::mul(f29::mul(den1, den2), p.T);
@@ -233,6 +240,10 @@ BZ_HD void encode_words(u64 out[4], const ed29_point& p) {
   y = f29::cneg(y, f29::is_negative(f29::mul(x, z_inv))); // B <= 2
   const fe29 s = f29::abs(f29::mul(den_inv, f29::sub(p.Z, f29::weak_reduce(y))));
   f29::to_words(out, s);
+}
+
+BZ_HD void encode_words(u64 out[4], const ed29_point& p) {
+  encode_words(out, p, [](const fe29& z) { return f29::pow22523(z); });
 }
 } // namespace ristretto29
 

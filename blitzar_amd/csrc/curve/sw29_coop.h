@@ -1,11 +1,11 @@
-// Latency-oriented doubling for the Weierstrass curves (see curve/ed29_coop.h for the idea): the
-// four lanes of a DPP quad hold the same point and split the two rounds of four independent field
+// Latency-oriented doubling for the Weierstrass curves: a lone lane needs the eight field products
+// of a doubling back to back.  Here the four lanes of a DPP quad hold the same point and split the two rounds of four independent field
 // products of RCB15 Alg. 9, so a doubling on the Horner chain of a single column costs two product
 // latencies instead of eight.  Device only; formulas and bounds are those of sw29::dbl.
 //
 // Compiler note (ROCm 7.2 hipcc): a DPP move whose result only feeds a subtraction gets folded into
 // `v_subrev_u32_dpp`, and that form was observed to produce wrong values in every lane but the
-// source lane (grumpkin's `sub<4>(quad_get<2>(h), quad_get<1>(h))`; tools/ubench history).  The
+// source lane (grumpkin's `sub<4>(quad_get<2>(h), quad_get<1>(h))`).  The
 // value is therefore passed through an empty asm statement, which keeps it a plain
 // `v_mov_b32_dpp`.
 #pragma once

@@ -8,7 +8,7 @@
 
 #include "blitzar_amd/csrc/curve/ed25519.h"
 #include "blitzar_amd/csrc/curve/ed29.h"
-#include "blitzar_amd/csrc/curve/ed29_coop.h"
+#include "blitzar_amd/csrc/curve/ed16_wave.h"
 #include "blitzar_amd/csrc/curve/sw29.h"
 #include "blitzar_amd/csrc/curve/sw29_coop.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
@@ -70,24 +70,43 @@ struct ed25519_msm {
   }
   // engine point -> caller generator layout (sxt_ristretto255)
   BZ_HD static void store_api_generator(u8* out, const point& p) { store_projective(out, p); }
-  // k_horner's dependent chain, run by all 64 lanes of one wavefront with the four lanes of
-  // every DPP quad sharing each doubling / addition (curve/ed29_coop.h):
+  // k_horner's dependent chain, run by one wavefront that holds the single accumulator spread over
+  // its 64 lanes (curve/ed16_wave.h: a row of 16 lanes per coordinate, a limb per lane):
   //   2^(c n) * acc + sum_{w < n} 2^(c w) * window_sums[w * stride]   (acc absent: top window first)
+  // The window sums are rewritten in place to their packed cached form (128 of the slot's 144 bytes).
   static constexpr bool has_wave_horner = true;
 #if defined(__HIPCC__)
-  __device__ static point wave_horner(point acc, bool have_acc, const point* window_sums,
+  __device__ static point wave_horner(const point& acc, bool have_acc, point* window_sums,
                                       u32 stride, u32 num_windows, u32 window_bits) {
-    const u32 role = threadIdx.x & 3;
-    u32 i = num_windows;
-    if (!have_acc) {
-      acc = window_sums[(num_windows - 1) * stride];
-      i = num_windows - 1;
+    const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
+    for (u32 w = c.lane; w < num_windows; w += 64) {
+      point* slot = window_sums + static_cast<size_t>(w) * stride;
+      const ed29_cached_packed q = ed29::pack(ed29::to_cached(*slot));
+      *reinterpret_cast<ed29_cached_packed*>(slot) = q;
     }
-    while (i-- > 0) {
-      for (u32 k = 0; k < window_bits; ++k) acc = ed29::dbl_coop4(acc, role);
-      acc = ed29::add_cached_coop4(acc, ed29::to_cached(window_sums[i * stride]), role);
+    ed16w::wave_lds_sync();
+    u32 state = ed16w::identity(c);
+    if (have_acc) state = ed16w::load_point(c, acc);
+    for (u32 i = num_windows; i-- > 0;) {
+      if (have_acc || i + 1 != num_windows) {
+        for (u32 k = 0; k < window_bits; ++k) state = ed16w::dbl(c, state);
+      }
+      const u32* q = reinterpret_cast<const u32*>(window_sums + static_cast<size_t>(i) * stride);
+      state = ed16w::add_cached(c, state, ed16w::load_words(c, q));
     }
-    return acc;
+    return ed16w::store_point(c, state);
+  }
+  // canonical encoding by a whole wavefront (every lane passes the same point, lane 0 writes): the
+  // inverse square root's 252 squarings run lane-parallel
+  static constexpr bool has_wave_encode = true;
+  __device__ static void wave_encode(u8* out, const point& p) {
+    const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
+    u64 w[4];
+    ristretto29::encode_words(w, p, [&c](const fe29& z) { return ed16w::pow22523(c, z); });
+    if (c.lane == 0) {
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) out[8 * i + j] = static_cast<u8>(w[i] >> (8 * j));
+    }
   }
 #endif
 };
@@ -122,11 +141,12 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr size_t api_generator_size = sizeof(api_affine);
   static constexpr size_t projective_size = sizeof(api_projective);
   static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
+  static constexpr bool has_wave_encode = false;
   // k_horner's dependent chain on one wavefront: doublings split over the lanes of each DPP quad
   // (curve/sw29_coop.h), the one addition per window computed redundantly by every lane
   static constexpr bool has_wave_horner = true;
 #if defined(__HIPCC__)
-  __device__ static point wave_horner(point acc, bool have_acc, const point* window_sums,
+  __device__ static point wave_horner(point acc, bool have_acc, point* window_sums,
                                       u32 stride, u32 num_windows, u32 window_bits) {
     const u32 role = threadIdx.x & 3;
     u32 i = num_windows;

@@ -494,9 +494,10 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 nb = 1u << (col.window_bits - 1);
   const u32 blocks = (nb + kReduceBlockBuckets - 1) / kReduceBlockBuckets;
   point sum = C::identity();
-  if (w < W) {
+  if (w < W && lane < blocks) {
     const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;
-    for (u32 blk = lane; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
+    sum = p[lane];
+    for (u32 blk = lane + team; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
   }
   tree[tid] = sum;
   __syncthreads();
@@ -525,14 +526,15 @@ __global__ void __launch_bounds__(kCombineThreads)
         acc = C::add(acc, tree[i * team]);
       }
     }
-    if (tid == 0) {
-      if (!last) {
-        state[blockIdx.x] = acc;
-      } else if (projective_out) {
-        C::store_projective(dst, acc);
-      } else {
-        C::encode(dst, acc);
-      }
+    // every lane of the wavefront holds the chain value
+    if (!last) {
+      if (tid == 0) state[blockIdx.x] = acc;
+    } else if (projective_out) {
+      if (tid == 0) C::store_projective(dst, acc);
+    } else if constexpr (C::has_wave_encode) {
+      C::wave_encode(dst, acc);
+    } else {
+      if (tid == 0) C::encode(dst, acc);
     }
   }
 }
