@@ -20,7 +20,12 @@ const curve_vtable* curve_vtable_for(unsigned curve_id) {
   }
 }
 
-msm_context* msm_context_new() { return new msm_context(); }
+msm_context* msm_context_new() {
+  auto* ctx = new msm_context();
+  // development overrides of the sort geometry (plan.h)
+  if (const char* v = std::getenv("BLITZAR_AMD_GROUP_ENTRIES")) ctx->tuning.partition_group_entries = std::strtoul(v, nullptr, 10);
+  return ctx;
+}
 void msm_context_free(msm_context* ctx) { delete ctx; }
 void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
                             size_t max_workspace_bytes) {

@@ -4,6 +4,7 @@
 // reference's).
 #pragma once
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -79,13 +80,16 @@ struct msm_context {
   stage_timer timer;
 };
 
-// one-time kernel attributes: the sort kernels need up to 128 KiB of dynamic LDS
+// one-time kernel attributes: the partition kernels keep one counter per bucket group in dynamic
+// LDS (a few KiB normally; up to 128 KiB for columns beyond 2^30 rows, plan.h)
 static void configure_sort_kernels() {
   static bool done = false;
   if (done) return;
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_hist),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_hist),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   done = true;
 }
@@ -101,9 +105,8 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   need += device_arena::padded(sizeof(task_desc) * (num_tasks + 1));
   if (needs_addends) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
   need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
-  need += device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
-  need += device_arena::padded(sizeof(u32) * (plan.total_hist + 2));
-  need += device_arena::padded(sizeof(u32) * (plan.total_chunks + 1));
+  need += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
+  need += 2 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
   need += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
   need += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
@@ -196,9 +199,10 @@ template <class C> struct batch_buffers {
   task_desc* tasks;
   const typename C::addend* addends;
   i16* digits;
+  u32* records;
   u32* sorted;
-  u32* hist;
-  u32* chunk_totals;
+  u32* group_cursor;
+  u32* group_start;
   u32* segment_bucket;
   u32* bucket_end;
   typename C::point* bucket_sums;
@@ -253,16 +257,17 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   }
   b.addends = d_addends;
   b.digits = ctx.arena.take<i16>(plan.total_entries + 8);
+  b.records = ctx.arena.take<u32>(plan.total_entries + 8);
   b.sorted = ctx.arena.take<u32>(plan.total_entries + 8);
-  b.hist = ctx.arena.take<u32>(plan.total_hist + 2);
-  b.chunk_totals = ctx.arena.take<u32>(plan.total_chunks + 1);
+  b.group_cursor = ctx.arena.take<u32>(plan.total_groups + 1);
+  b.group_start = ctx.arena.take<u32>(plan.total_groups + 1);
   b.segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
   b.bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
   b.bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
   b.heads = ctx.arena.take<point>(plan.total_segments + 1);
   b.partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * b.partial_stride + 1);
   b.horner_state = ctx.arena.take<point>(num_cols);
-  const size_t sort_lds = sizeof(u32) * plan.max_task_buckets;
+  const size_t part_lds = sizeof(u32) * plan.max_task_groups;
   const u32 seg_blocks =
       ceil_div_u32(plan.max_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
 
@@ -278,24 +283,26 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     hipLaunchKernelGGL(k_recode, dim3(ceil_div_u32(plan.max_rows, 256), num_cols), dim3(256), 0,
                        stream, b.digits, b.cols, b.tasks);
   });
-  BZ_HIP_CHECK(hipMemsetAsync(b.chunk_totals, 0, sizeof(u32) * (plan.total_chunks + 1), stream));
+  BZ_HIP_CHECK(hipMemsetAsync(b.group_cursor, 0, sizeof(u32) * (plan.total_groups + 1), stream));
   ctx.timer.timed(timing, 2, stream, [&] {
-    hipLaunchKernelGGL(k_bucket_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       sort_lds, stream, b.hist, b.chunk_totals, b.digits, b.tasks);
-    hipLaunchKernelGGL(k_bucket_offsets,
-                       dim3(ceil_div_u32(plan.max_task_buckets, kOffsetChunkBuckets), num_tasks),
-                       dim3(256), 0, stream, b.hist, b.bucket_end, b.chunk_totals, b.tasks);
-    // bucket ranges of <= ~1 MiB of sorted entries each (see k_bucket_scatter)
-    u32 ranges = ceil_div_u32(plan.max_rows * sizeof(u32), ctx.tuning.scatter_range_bytes);
-    if (ranges > 8) ranges = 8; // every range re-reads the slice's digits
-    if (ranges > plan.max_task_buckets) ranges = plan.max_task_buckets;
-    if (ranges < 1) ranges = 1;
-    const u32 units = num_tasks * ranges;
-    const u32 blocks = 8 * plan.max_task_slices * ceil_div_u32(units, 8);
-    const size_t scatter_lds = sizeof(u32) * ceil_div_u32(plan.max_task_buckets, ranges);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(kSortThreads), scatter_lds, stream,
-                       b.sorted, b.segment_bucket, b.hist, b.digits, b.tasks, num_tasks, ranges,
-                       plan.max_task_slices);
+    hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
+                       part_lds, stream, b.group_cursor, b.digits, b.tasks);
+    hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, stream, b.group_cursor,
+                       b.group_start, b.tasks);
+    // all tasks of a launch share one variant: staged unless some column needs the direct form
+    if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
+      const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
+      hipLaunchKernelGGL(k_group_scatter<true>, dim3(plan.max_task_slices, num_tasks),
+                         dim3(kSortThreads), staged_lds, stream, b.records, b.group_cursor,
+                         b.digits, b.tasks);
+    } else {
+      hipLaunchKernelGGL(k_group_scatter<false>, dim3(plan.max_task_slices, num_tasks),
+                         dim3(kSortThreads), part_lds, stream, b.records, b.group_cursor, b.digits,
+                         b.tasks);
+    }
+    hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads), 0,
+                       stream, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                       b.tasks);
   });
   ctx.timer.timed(timing, 3, stream, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
@@ -314,7 +321,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        b.partial_stride, b.cols, b.tasks, b.bucket_end, 0u, 0xffffffffu, 1, 1);
   });
   if (timing) ctx.timer.calls += 1;
-  g_kernel_launches += 7;
+  g_kernel_launches += 8;
   BZ_HIP_CHECK(hipGetLastError());
 }
 

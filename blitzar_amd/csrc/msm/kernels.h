@@ -6,11 +6,12 @@
 //   k_recode           scalars -> signed radix-2^c digits, transposed to [task][row] int16
 //                      (reference: mtxb digit extraction, sxt/multiexp/base/digit_utility.cc:27-98,
 //                       and the scalar transpose sxt/multiexp/base/scalar_array.cc:34-104)
-//   k_bucket_hist      per (task, 64 Ki-row slice): LDS histogram of the digits -> global counts
-//   k_bucket_offsets   per (task, 512 buckets): exclusive scan over (bucket, slice) -> the start
-//                      offset of every slice's share of every bucket + bucket end offsets
-//   k_bucket_scatter   per (task, slice): LDS cursors, scatter of `row | sign << 31`
-//                      (together a counting sort by bucket; reference K1/K2:
+//   k_group_hist       per (task, slice of rows): LDS histogram of the digits by bucket *group*
+//   k_group_offsets    per task: exclusive scan of the group totals -> start of every group
+//   k_group_scatter    per (task, slice): partition the digits into per-group runs of records
+//   k_group_sort       per (task, group): counting sort of the group by bucket inside LDS ->
+//                      `row | sign << 31` list, bucket end offsets, segment -> bucket map
+//                      (together a two-pass radix sort by bucket; reference K1/K2:
 //                       bucket_method2/multiproduct_table_kernel.h:32-93, multiproduct_table.cc:74-82)
 //   k_accumulate       one lane per 32 consecutive *sorted entries* (not per bucket): gather
 //                      addends, mixed-add, flush at bucket boundaries; a bucket that straddles
@@ -74,13 +75,14 @@ static __global__ void __launch_bounds__(256)
 }
 
 //--------------------------------------------------------------------------------------------------
-// counting sort by bucket: k_bucket_hist -> k_bucket_offsets -> k_bucket_scatter
+// sort by bucket: k_group_hist -> k_group_offsets -> k_group_scatter (partition by bucket group)
+// -> k_group_sort (counting sort of one group inside LDS)
 //--------------------------------------------------------------------------------------------------
-// The three kernels visit the digits of a (task, slice) in the same vectorised order.  `fn(r, e)`
+// Both partition sweeps visit the digits of a (task, slice) in the same vectorised order.  `fn(r, e)`
 // is called for every non-zero stored digit e = -D of row r (relative to the slice).
 template <class F>
 __device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig, u32 rows, F&& fn) {
-  // slices start at multiples of kSliceRows and entry ranges are padded to multiples of 8
+  // slices start at multiples of 8 rows and entry ranges are padded to multiples of 8
   // entries, so 16-byte vector loads are aligned and in bounds
   const u32 nvec = (rows + 7) / 8;
   const uint4* dig4 = reinterpret_cast<const uint4*>(dig);
@@ -96,79 +98,243 @@ __device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig
   }
 }
 
-// counts[task.hist_base + slice * nb + b] = digits of the slice in bucket b;
-// chunk_totals[task.chunk_base + b / 512] += the slice's digits in that chunk of buckets
+// Pass 1a.  group_total[task.group_base + g] += digits of the slice whose bucket lies in group g
+// (2^s consecutive buckets): LDS histogram, one global atomic per populated group.
 static __global__ void __launch_bounds__(kSortThreads)
-    k_bucket_hist(u32* __restrict__ counts, u32* __restrict__ chunk_totals,
-                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
+    k_group_hist(u32* __restrict__ group_total, const i16* __restrict__ digits,
+                 const task_desc* __restrict__ tasks) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const task_desc task = tasks[blockIdx.y];
   const u32 slice = blockIdx.x;
   if (slice >= task.num_slices) return;
-  const u32 nb = task.num_buckets;
+  const u32 groups = task.num_groups, s = task.group_bits;
   const u32 tid = threadIdx.x;
-  for (u32 b = tid; b < nb; b += kSortThreads) lds[b] = 0;
+  for (u32 g = tid; g < groups; g += kSortThreads) lds[g] = 0;
   __syncthreads();
-  const u64 row0 = static_cast<u64>(slice) * kSliceRows;
-  const u32 rows = static_cast<u32>(task.rows - row0 < kSliceRows ? task.rows - row0 : kSliceRows);
+  const u64 row0 = static_cast<u64>(slice) * task.slice_rows;
+  const u32 rows =
+      static_cast<u32>(task.rows - row0 < task.slice_rows ? task.rows - row0 : task.slice_rows);
   for_each_slice_digit(digits + task.entry_base + row0, rows, [&](u32, int e) {
     const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
-    atomicAdd(&lds[mag - 1], 1u);
+    atomicAdd(&lds[(mag - 1) >> s], 1u);
   });
   __syncthreads();
-  u32* out = counts + task.hist_base + static_cast<u64>(slice) * nb;
-  for (u32 b = tid; b < nb; b += kSortThreads) out[b] = lds[b];
-  // per-chunk totals: one wave per chunk, 8 counters per lane at the full chunk size
-  const u32 lane = tid & 63, wave = tid >> 6;
-  const u32 chunks = (nb + kOffsetChunkBuckets - 1) / kOffsetChunkBuckets;
-  for (u32 ch = wave; ch < chunks; ch += kSortThreads / 64) {
-    u32 sum = 0;
-    for (u32 k = lane; k < kOffsetChunkBuckets; k += 64) {
-      const u32 b = ch * kOffsetChunkBuckets + k;
-      if (b < nb) sum += lds[b];
-    }
-#pragma unroll
-    for (u32 off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-    if (lane == 0 && sum != 0) atomicAdd(&chunk_totals[task.chunk_base + ch], sum);
+  u32* out = group_total + task.group_base;
+  for (u32 g = tid; g < groups; g += kSortThreads) {
+    if (lds[g] != 0) atomicAdd(&out[g], lds[g]);
   }
 }
 
-// In place: counts[slice][b] becomes the offset (inside the task's sorted entry list) at which the
-// slice's digits of bucket b start; bucket_end[bucket_base + b] = end offset of bucket b.
-// Order of the sorted list: bucket-major, slices in order inside a bucket.
+// Pass 1b, one workgroup per task: exclusive scan of the group totals.
+//   group_start[task.group_base + g] = first record of group g, entry [G] = records of the task;
+//   group_cursor (the totals, in place) = the same offsets, bumped by k_group_scatter.
 static __global__ void __launch_bounds__(256)
-    k_bucket_offsets(u32* __restrict__ counts, u32* __restrict__ bucket_end,
-                     const u32* __restrict__ chunk_totals, const task_desc* __restrict__ tasks) {
+    k_group_offsets(u32* __restrict__ group_cursor, u32* __restrict__ group_start,
+                    const task_desc* __restrict__ tasks) {
   __shared__ u32 wave_sums[4];
-  __shared__ u32 chunk_base_sh;
-  const task_desc task = tasks[blockIdx.y];
-  const u32 nb = task.num_buckets;
-  const u32 ch = blockIdx.x;
-  if (ch * kOffsetChunkBuckets >= nb) return;
+  const task_desc task = tasks[blockIdx.x];
+  const u32 groups = task.num_groups;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave == 0) {
-    u32 s = 0;
-    for (u32 k = lane; k < ch; k += 64) s += chunk_totals[task.chunk_base + k];
+  u32* cur = group_cursor + task.group_base;
+  u32* gs = group_start + task.group_base;
+  u32 carry = 0;
+  for (u32 g0 = 0; g0 < groups; g0 += 256) {
+    const u32 g = g0 + tid;
+    const u32 total = g < groups ? cur[g] : 0;
+    u32 incl = total;
 #pragma unroll
-    for (u32 off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) chunk_base_sh = s;
-  }
-  // two adjacent buckets per lane
-  const u32 b0 = ch * kOffsetChunkBuckets + 2 * tid;
-  u32* col = counts + task.hist_base + b0;
-  const bool in0 = b0 < nb, in1 = b0 + 1 < nb;
-  u32 t0 = 0, t1 = 0;
-  if (in1) {
-    for (u32 s = 0; s < task.num_slices; ++s) {
-      const uint2 v = *reinterpret_cast<const uint2*>(col + static_cast<u64>(s) * nb);
-      t0 += v.x;
-      t1 += v.y;
+    for (u32 off = 1; off < 64; off <<= 1) {
+      const u32 up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
     }
-  } else if (in0) {
-    for (u32 s = 0; s < task.num_slices; ++s) t0 += col[static_cast<u64>(s) * nb];
+    __syncthreads(); // wave_sums of the previous round have been read
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    u32 base = carry;
+    for (u32 w = 0; w < wave; ++w) base += wave_sums[w];
+    if (g < groups) {
+      gs[g] = base + incl - total;
+      cur[g] = base + incl - total;
+    }
+    carry += wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
   }
-  // exclusive scan of the 512 bucket totals in bucket order
-  const u32 local = t0 + t1;
+  if (tid == 0) gs[groups] = carry;
+}
+
+// the eight stored digits E = -D of one 16-byte vector
+__device__ __forceinline__ void unpack_digits(const uint4& pack, int e[8]) {
+  const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = static_cast<i16>(words[k >> 1] >> (16 * (k & 1)));
+}
+
+// Pass 1c.  Every non-zero digit of the slice becomes one 32-bit record in its group's piece of
+// the record list:
+//   record = (digit negative) << 31 | (bucket mod 2^s) << (31 - s) | row        (row < 2^(31-s))
+// The workgroup histograms its slice by group and claims one contiguous run per group with a
+// global atomic on the group's cursor (so the order of the runs inside a group is arbitrary;
+// bucket contents are order-free).  Scattered 4-byte stores cost one L2 transaction each (16.8 M
+// of them at config 2, ~80 us), so the Staged variant first assembles the slice's records grouped
+// in LDS and then copies every run out with whole-line stores, one wavefront per run; the direct
+// variant (more than kMaxStagedGroups groups: columns beyond ~2^25 rows) stores records one by
+// one.  Per vector the eight cursor bumps are issued before the eight dependent stores.
+//   dynamic LDS: Staged ? 3 * groups + 1 + kStagedSliceRows : groups   words
+template <bool Staged>
+__global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
+    k_group_scatter(u32* __restrict__ records, u32* __restrict__ group_cursor,
+                    const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  __shared__ u32 wave_sums[kSortThreads / 64];
+  const task_desc task = tasks[blockIdx.y];
+  const u32 slice = blockIdx.x;
+  if (slice >= task.num_slices) return;
+  const u32 groups = task.num_groups, s = task.group_bits;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  u32* cursor = lds;                  // [groups]     count, then write cursor of every group
+  u32* local_start = lds + groups;    // [groups + 1] Staged: first staged record of the group
+  u32* run_base = lds + 2 * groups + 1; // [groups]   Staged: where the run goes in `records`
+  u32* staging = lds + 3 * groups + 1;  // [kStagedSliceRows]
+  for (u32 g = tid; g < groups; g += kSortThreads) cursor[g] = 0;
+  __syncthreads();
+  const u64 row0 = static_cast<u64>(slice) * task.slice_rows;
+  const u32 rows =
+      static_cast<u32>(task.rows - row0 < task.slice_rows ? task.rows - row0 : task.slice_rows);
+  const u32 nvec = (rows + 7) / 8;
+  const uint4* dig4 = reinterpret_cast<const uint4*>(digits + task.entry_base + row0);
+  // the first two vectors of every thread stay in registers (all of them at 16384-row slices)
+  uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  if (tid < nvec) held[0] = dig4[tid];
+  if (tid + kSortThreads < nvec) held[1] = dig4[tid + kSortThreads];
+  auto vector_at = [&](u32 v) {
+    return v == tid ? held[0] : (v == tid + kSortThreads ? held[1] : dig4[v]);
+  };
+  for (u32 v = tid; v < nvec; v += kSortThreads) {
+    int e[8];
+    unpack_digits(vector_at(v), e);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 mag = e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k]);
+      if (v * 8 + k < rows && e[k] != 0) atomicAdd(&cursor[(mag - 1) >> s], 1u);
+    }
+  }
+  __syncthreads();
+  u32* cur = group_cursor + task.group_base;
+  if constexpr (Staged) {
+    // groups <= kSortThreads: one group per thread; exclusive scan of the counts
+    const u32 count = tid < groups ? cursor[tid] : 0;
+    u32 incl = count;
+#pragma unroll
+    for (u32 off = 1; off < 64; off <<= 1) {
+      const u32 up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    u32 start = incl - count;
+    for (u32 w = 0; w < wave; ++w) start += wave_sums[w];
+    if (tid < groups) {
+      cursor[tid] = start;
+      local_start[tid] = start;
+      run_base[tid] = count != 0 ? atomicAdd(&cur[tid], count) : 0;
+      if (tid + 1 == groups) local_start[groups] = start + count;
+    }
+  } else {
+    for (u32 g = tid; g < groups; g += kSortThreads) {
+      const u32 count = cursor[g];
+      cursor[g] = count != 0 ? atomicAdd(&cur[g], count) : 0;
+    }
+  }
+  __syncthreads();
+  u32* out = records + task.entry_base;
+  const u32 in_group = (1u << s) - 1, shift = 31 - s;
+  for (u32 v = tid; v < nvec; v += kSortThreads) {
+    int e[8];
+    unpack_digits(vector_at(v), e);
+    u32 pos[8], rec[8];
+    bool take[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      // E = -D: positive E means the digit is negative -> subtract the generator
+      const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
+      take[k] = v * 8 + k < rows && e[k] != 0;
+      rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
+               (static_cast<u32>(row0) + v * 8 + k);
+      pos[k] = 0;
+      if (take[k]) pos[k] = atomicAdd(&cursor[bucket >> s], 1u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (take[k]) {
+        if constexpr (Staged) {
+          staging[pos[k]] = rec[k];
+        } else {
+          out[pos[k]] = rec[k];
+        }
+      }
+    }
+  }
+  if constexpr (Staged) {
+    __syncthreads();
+    for (u32 g = wave; g < groups; g += kSortThreads / 64) {
+      const u32 from = local_start[g], count = local_start[g + 1] - from;
+      u32* dst = out + run_base[g];
+      for (u32 i = lane; i < count; i += 64) dst[i] = staging[from + i];
+    }
+  }
+}
+
+// Pass 2, one workgroup per (task, group): counting sort of the group's records by bucket.
+//   sorted[task.entry_base + pos] = row | (digit negative) << 31, grouped by bucket;
+//   bucket_end[task.bucket_base + b] = end offset of bucket b in the task's sorted list;
+//   segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment.
+// A group of at most kLocalSortCapacity records (the normal case) is held in registers, its piece
+// of the sorted list assembled in LDS and written out in order (coalesced); a larger group
+// (skewed digits, very long columns) streams its records twice and writes its piece directly.
+constexpr u32 kGroupSortThreads = 512;
+constexpr u32 kLocalSortPerThread = kLocalSortCapacity / kGroupSortThreads;
+static_assert(kLocalSortPerThread * kGroupSortThreads == kLocalSortCapacity);
+static_assert(2 * kGroupSortThreads >= (1u << kMaxGroupBits));
+
+static __global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                 u32* __restrict__ bucket_end, const u32* __restrict__ records,
+                 const u32* __restrict__ group_start, const task_desc* __restrict__ tasks) {
+  __shared__ u32 cursor[1u << kMaxGroupBits];
+  __shared__ u32 staging[kLocalSortCapacity];
+  __shared__ u32 wave_sums[kGroupSortThreads / 64];
+  const task_desc task = tasks[blockIdx.y];
+  const u32 g = blockIdx.x;
+  if (g >= task.num_groups) return;
+  const u32 s = task.group_bits, buckets = 1u << s;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32* gs = group_start + task.group_base;
+  const u32 begin = gs[g], total = gs[g + 1] - begin;
+  for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
+  __syncthreads();
+  const u32* rec = records + task.entry_base + begin;
+  const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
+  const bool staged = total <= kLocalSortCapacity; // uniform over the workgroup
+  u32 mine[kLocalSortPerThread];
+  if (staged) {
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      const u32 i = tid + k * kGroupSortThreads;
+      mine[k] = i < total ? rec[i] : 0;
+    }
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      if (tid + k * kGroupSortThreads < total) atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+    }
+  } else {
+    for (u32 i = tid; i < total; i += kGroupSortThreads) {
+      atomicAdd(&cursor[(rec[i] >> shift) & in_group], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the <= 2^kMaxGroupBits bucket counts, two adjacent buckets per lane
+  const u32 b0 = 2 * tid;
+  const u32 c0 = b0 < buckets ? cursor[b0] : 0, c1 = b0 + 1 < buckets ? cursor[b0 + 1] : 0;
+  const u32 local = c0 + c1;
   u32 incl = local;
 #pragma unroll
   for (u32 off = 1; off < 64; off <<= 1) {
@@ -177,77 +343,50 @@ static __global__ void __launch_bounds__(256)
   }
   if (lane == 63) wave_sums[wave] = incl;
   __syncthreads();
-  u32 base = chunk_base_sh;
-  for (u32 w = 0; w < wave; ++w) base += wave_sums[w];
-  u32 run0 = base + incl - local;
-  u32 run1 = run0 + t0;
-  if (in0) bucket_end[task.bucket_base + b0] = run0 + t0;
-  if (in1) bucket_end[task.bucket_base + b0 + 1] = run1 + t1;
-  if (in1) {
-    for (u32 s = 0; s < task.num_slices; ++s) {
-      uint2* p = reinterpret_cast<uint2*>(col + static_cast<u64>(s) * nb);
-      const uint2 v = *p;
-      *p = make_uint2(run0, run1);
-      run0 += v.x;
-      run1 += v.y;
+  u32 start0 = incl - local;
+  for (u32 w = 0; w < wave; ++w) start0 += wave_sums[w];
+  const u32 start1 = start0 + c0;
+  u32* ends = bucket_end + task.bucket_base + (static_cast<u64>(g) << s);
+  if (b0 < buckets) {
+    cursor[b0] = start0;
+    ends[b0] = begin + start0 + c0;
+  }
+  if (b0 + 1 < buckets) {
+    cursor[b0 + 1] = start1;
+    ends[b0 + 1] = begin + start1 + c1;
+  }
+  __syncthreads();
+  u32* out = sorted + task.entry_base + begin;
+  u32* seg = segment_bucket + task.segment_base;
+  if (staged) {
+    u32 pos[kLocalSortPerThread];
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      pos[k] = 0;
+      if (tid + k * kGroupSortThreads < total) {
+        pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+      }
     }
-  } else if (in0) {
-    for (u32 s = 0; s < task.num_slices; ++s) {
-      u32* p = col + static_cast<u64>(s) * nb;
-      const u32 v = *p;
-      *p = run0;
-      run0 += v;
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      if (tid + k * kGroupSortThreads < total) {
+        staging[pos[k]] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
+        if ((begin + pos[k]) % kSegmentEntries == 0) {
+          seg[(begin + pos[k]) / kSegmentEntries] = (g << s) + ((mine[k] >> shift) & in_group);
+        }
+      }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < total; i += kGroupSortThreads) out[i] = staging[i];
+  } else {
+    for (u32 i = tid; i < total; i += kGroupSortThreads) {
+      const u32 r = rec[i];
+      const u32 b = (r >> shift) & in_group;
+      const u32 pos = atomicAdd(&cursor[b], 1u);
+      out[pos] = (r & 0x80000000u) | (r & row_mask);
+      if ((begin + pos) % kSegmentEntries == 0) seg[(begin + pos) / kSegmentEntries] = (g << s) + b;
     }
   }
-}
-
-// sorted[task.entry_base + pos] = row | (digit negative) << 31, grouped by bucket;
-// segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment.
-//
-// The scatter writes 4 bytes to an essentially random position of the task's sorted list, so its
-// speed is set by how many of those writes merge into full lines before they leave the L2
-// (measured: 0.16 of the 0.22 ms of this kernel at config 2 are the random writes).  Work is
-// therefore cut by *bucket range* as well: a unit = (task, 1/Q of the buckets) owns a contiguous
-// <= ~1 MiB piece of the sorted list, its slices (one workgroup each) re-read the slice's digits
-// and keep only their bucket range, and the block index is laid out so that all slices of a unit
-// -- and only two units at a time -- land on the same XCD (observed placement: block b -> XCD
-// b % 8; used for L2 affinity only, results do not depend on it).
-static __global__ void __launch_bounds__(kSortThreads)
-    k_bucket_scatter(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                     const u32* __restrict__ offsets, const i16* __restrict__ digits,
-                     const task_desc* __restrict__ tasks, u32 num_tasks, u32 ranges_per_task,
-                     u32 slices_per_unit) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  // block = xcd + 8 * (slice + slices_per_unit * unit_group), unit = 8 * unit_group + xcd
-  const u32 xcd = blockIdx.x & 7;
-  const u32 rest = blockIdx.x >> 3;
-  const u32 slice = rest % slices_per_unit;
-  const u32 unit = (rest / slices_per_unit) * 8 + xcd;
-  if (unit >= num_tasks * ranges_per_task) return;
-  const task_desc task = tasks[unit / ranges_per_task];
-  if (slice >= task.num_slices) return;
-  const u32 nb = task.num_buckets;
-  const u32 range = unit % ranges_per_task;
-  const u32 per_range = (nb + ranges_per_task - 1) / ranges_per_task;
-  const u32 b_lo = range * per_range;
-  if (b_lo >= nb) return;
-  const u32 b_hi = b_lo + per_range < nb ? b_lo + per_range : nb;
-  const u32 tid = threadIdx.x;
-  const u32* in = offsets + task.hist_base + static_cast<u64>(slice) * nb + b_lo;
-  for (u32 b = tid; b < b_hi - b_lo; b += kSortThreads) lds[b] = in[b];
-  __syncthreads();
-  const u64 row0 = static_cast<u64>(slice) * kSliceRows;
-  const u32 rows = static_cast<u32>(task.rows - row0 < kSliceRows ? task.rows - row0 : kSliceRows);
-  u32* out = sorted + task.entry_base;
-  u32* seg = segment_bucket + task.segment_base;
-  for_each_slice_digit(digits + task.entry_base + row0, rows, [&](u32 r, int e) {
-    // E = -D: positive E means the digit is negative -> subtract the generator
-    const u32 bucket = (e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e)) - 1;
-    if (bucket < b_lo || bucket >= b_hi) return;
-    const u32 pos = atomicAdd(&lds[bucket - b_lo], 1u);
-    out[pos] = (static_cast<u32>(row0) + r) | (e > 0 ? 0x80000000u : 0u);
-    if (pos % kSegmentEntries == 0) seg[pos / kSegmentEntries] = bucket;
-  });
 }
 
 //--------------------------------------------------------------------------------------------------

@@ -6,10 +6,12 @@
 //   * a window is one signed radix-2^c digit position of the column's scalars.
 // Every task owns 2^(c-1) buckets (bucket id = |digit| - 1).  The column result is
 //   sum_w 2^(c w) * sum_b (b + 1) * bucket[w][b].
-// Inside a task the rows are cut into *slices* (kSliceRows rows, one workgroup each) for the
-// counting sort, and the sorted entry list is cut into *segments* (kSegmentEntries entries, one
-// lane each) for the bucket accumulation, so the parallelism of every stage is proportional to
-// the number of rows and independent of how the digits are distributed over the buckets.
+// The digits of a task are sorted by bucket in two passes (kernels.h): the buckets are cut into
+// *groups* of 2^s consecutive buckets, the rows into *slices* (one workgroup each); pass 1
+// partitions every slice's digits by group, pass 2 sorts one group per workgroup inside LDS.  The
+// sorted entry list is then cut into *segments* (kSegmentEntries entries, one lane each) for the
+// bucket accumulation, so the parallelism of every stage is proportional to the number of rows
+// and independent of how the digits are distributed over the buckets.
 //
 // This replaces, as one mechanism, the reference's three dispatch tiers
 // (sxt/multiexp/curve/multiexponentiation.h:147-200: bucket_method2 / bucket_method / generic
@@ -23,9 +25,14 @@
 
 namespace bz {
 
-constexpr u32 kSliceRows = 1u << 16;    // rows per counting-sort workgroup
-constexpr u32 kSegmentEntries = 32;     // sorted entries per accumulation lane
-constexpr u32 kOffsetChunkBuckets = 512; // buckets per k_bucket_offsets workgroup
+constexpr u32 kSegmentEntries = 32;       // sorted entries per accumulation lane
+constexpr u32 kStagedSliceRows = 1u << 14; // rows per partition workgroup: staged in LDS / direct
+constexpr u32 kDirectSliceRows = 1u << 16;
+constexpr u32 kMaxStagedGroups = 1024;     // the staged partition keeps 3 counters per group in LDS
+constexpr u32 kGroupTargetEntries = 4096; // entries a bucket group should hold (uniform digits)
+constexpr u32 kLocalSortCapacity = 6144;  // entries the per-group sort stages in LDS
+constexpr u32 kMaxGroupBits = 10;         // 2^s counters of the per-group sort live in LDS
+constexpr u32 kMaxGroupsLog2 = 10;        // pass 1 writes one stream per group: keep them few
 
 // buckets a reduce block covers (threads per block x buckets per thread), shared with kernels.h
 constexpr u32 kReduceThreads = 256;
@@ -38,13 +45,15 @@ struct task_desc {
   u32 window;
   u64 rows;         // rows of the column
   u32 num_buckets;  // 2^(c-1)
-  u32 num_slices;   // ceil(rows / kSliceRows)
-  u64 bucket_base;  // first bucket of this task in the flat bucket arrays
-  u64 entry_base;   // first entry of this task in the flat digit / sorted-index arrays
-  u64 hist_base;    // first counter of this task's [slice][bucket] histogram
-  u64 segment_base; // first segment of this task in the flat per-segment arrays
-  u32 chunk_base;   // first k_bucket_offsets chunk total of this task
+  u32 num_slices;   // ceil(rows / slice_rows)
+  u32 slice_rows;   // rows per partition workgroup (power of two, multiple of 8)
+  u32 group_bits;   // s: a group is 2^s consecutive buckets
+  u32 num_groups;   // num_buckets >> s
   u32 pad;
+  u64 bucket_base;  // first bucket of this task in the flat bucket arrays
+  u64 entry_base;   // first entry of this task in the flat digit / record / sorted-index arrays
+  u64 group_base;   // first entry of this task's group tables (num_groups + 1 entries)
+  u64 segment_base; // first segment of this task in the flat per-segment arrays
 };
 
 // device-visible column descriptor
@@ -65,25 +74,26 @@ struct msm_plan {
   std::vector<task_desc> tasks;
   u64 total_buckets = 0;
   u64 total_entries = 0;
-  u64 total_hist = 0;
+  u64 total_groups = 0;    // entries of all group tables (group_start, group_cursor)
   u64 total_segments = 0;
-  u32 total_chunks = 0;
   u64 max_rows = 0;        // longest column
   u32 max_task_buckets = 0;
   u32 max_task_slices = 0;
+  u32 max_task_groups = 0;
+  u32 max_slice_rows = 0;
   u32 max_windows = 0;
 };
 
 struct msm_tuning {
-  u32 max_window_bits = 16; // the LDS histogram holds 2^(c-1) 32-bit counters (128 KiB at c = 16)
+  u32 max_window_bits = 16; // digits are stored as int16
   // batching of many-column jobs: tasks per launch (grid.y) and device workspace per batch
   size_t max_tasks_per_batch = 32768;
   size_t max_workspace_bytes = size_t{64} << 30;
+  // two-pass sort geometry (choose_partition below): entries per bucket group
+  u32 partition_group_entries = kGroupTargetEntries;
   // window-width cost model: from this many columns on, buckets cost `throughput_bucket_cost`
   size_t throughput_columns = 4;
   double throughput_bucket_cost = 12.0;
-  // k_bucket_scatter: bytes of sorted entries one (task, bucket range) unit covers
-  size_t scatter_range_bytes = size_t{1} << 19;
 };
 
 inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b); }
@@ -126,6 +136,41 @@ inline host_column byte_column(const u8* data, u64 n, u32 nbytes, bool is_signed
   return host_column{data, n, nbytes, 0, 8 * nbytes, is_signed};
 }
 
+// Partition geometry of a task with n rows and 2^(c-1) buckets.
+//   s (group_bits): groups of ~kGroupTargetEntries entries so that pass 2 sorts a group inside
+//     LDS; bounded by the 32-bit partition record, which packs sign | bucket-in-group (s bits) |
+//     row (31 - s bits), by the LDS counters of pass 2, and from below so that pass 1 keeps at
+//     most 2^kMaxGroupsLog2 output streams whenever the record has room for it.  For very long
+//     columns s shrinks to 0 and the scheme degenerates into a plain one-pass bucket scatter.
+//   slice_rows: what pass 1 can stage in LDS (so that it writes whole runs, not single records);
+//     with more than kMaxStagedGroups groups it writes records directly, from larger slices.
+struct partition_geometry {
+  u32 group_bits, num_groups, slice_rows, num_slices;
+};
+inline partition_geometry choose_partition(u64 n, u32 window_bits,
+                                            u32 target_entries = kGroupTargetEntries) {
+  const u32 bucket_bits = window_bits - 1;
+  u32 row_bits = 0;
+  while (row_bits < 31 && (u64{1} << row_bits) < n) ++row_bits;
+  // desired: largest s with n * 2^s / 2^bucket_bits <= kGroupTargetEntries
+  u32 desired = 0;
+  while (desired < bucket_bits &&
+         ((n << (desired + 1)) >> bucket_bits) <= target_entries)
+    ++desired;
+  const u32 few_streams = bucket_bits > kMaxGroupsLog2 ? bucket_bits - kMaxGroupsLog2 : 0;
+  u32 s = desired > few_streams ? desired : few_streams;
+  if (s > bucket_bits) s = bucket_bits;
+  if (s > kMaxGroupBits) s = kMaxGroupBits;
+  if (s > 31 - row_bits) s = 31 - row_bits;
+  partition_geometry g;
+  g.group_bits = s;
+  g.num_groups = 1u << (bucket_bits - s);
+  const u64 slice = g.num_groups <= kMaxStagedGroups ? kStagedSliceRows : kDirectSliceRows;
+  g.slice_rows = static_cast<u32>(slice);
+  g.num_slices = static_cast<u32>((n + slice - 1) / slice);
+  return g;
+}
+
 inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tuning& tune = {}) {
   msm_plan plan;
   plan.columns.reserve(cols.size());
@@ -152,7 +197,9 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     const u32 c = choose_window_bits(hc.n, bits, tune, bucket_cost);
     const u32 w = ceil_div_u32(bits + 1, c);
     const u32 buckets = 1u << (c - 1);
-    const u32 slices = ceil_div_u32(hc.n, kSliceRows);
+    const partition_geometry geo =
+        choose_partition(hc.n, c, tune.partition_group_entries);
+    const u32 slices = geo.num_slices;
     cd.window_bits = c;
     cd.num_windows = w;
     for (u32 wi = 0; wi < w; ++wi) {
@@ -162,21 +209,24 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       t.rows = hc.n;
       t.num_buckets = buckets;
       t.num_slices = slices;
+      t.slice_rows = geo.slice_rows;
+      t.group_bits = geo.group_bits;
+      t.num_groups = geo.num_groups;
       t.bucket_base = plan.total_buckets;
       t.entry_base = plan.total_entries;
-      t.hist_base = plan.total_hist;
+      t.group_base = plan.total_groups;
       t.segment_base = plan.total_segments;
-      t.chunk_base = plan.total_chunks;
       plan.total_buckets += buckets;
       // keep every task's entry range 16-byte aligned for both the i16 and the u32 views
       plan.total_entries += (hc.n + 7) & ~7ull;
-      plan.total_hist += static_cast<u64>(slices) * buckets;
+      plan.total_groups += geo.num_groups + 1;
       plan.total_segments += (hc.n + kSegmentEntries - 1) / kSegmentEntries;
-      plan.total_chunks += ceil_div_u32(buckets, kOffsetChunkBuckets);
       plan.tasks.push_back(t);
     }
     if (buckets > plan.max_task_buckets) plan.max_task_buckets = buckets;
     if (slices > plan.max_task_slices) plan.max_task_slices = slices;
+    if (geo.num_groups > plan.max_task_groups) plan.max_task_groups = geo.num_groups;
+    if (geo.slice_rows > plan.max_slice_rows) plan.max_slice_rows = geo.slice_rows;
     if (w > plan.max_windows) plan.max_windows = w;
     if (hc.n > plan.max_rows) plan.max_rows = hc.n;
     plan.columns.push_back(cd);

@@ -155,8 +155,9 @@ int bz_recode(int* digits, const u8* row, u32 bit_offset, u32 bit_width, int is_
   return static_cast<int>(num_windows);
 }
 
-// planner (msm/plan.h): per column {window_bits, num_windows, slices, first_task};
-// totals {tasks, total_buckets, total_entries, total_segments, rows covered, total_hist}
+// planner (msm/plan.h): per column {window_bits, num_windows, slices, first_task, slice_rows,
+// group_bits}; totals {tasks, total_buckets, total_entries, total_segments, rows covered,
+// total_groups}
 void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, const int* is_signed,
              u32 num_columns, u32 max_window_bits) {
   std::vector<host_column> cols(num_columns);
@@ -168,10 +169,12 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
   msm_plan plan = make_msm_plan(cols, tune);
   for (u32 i = 0; i < num_columns; ++i) {
     const column_desc& c = plan.columns[i];
-    per_column[4 * i + 0] = c.window_bits;
-    per_column[4 * i + 1] = c.num_windows;
-    per_column[4 * i + 2] = c.num_windows == 0 ? 0 : plan.tasks[c.first_task].num_slices;
-    per_column[4 * i + 3] = c.first_task;
+    per_column[6 * i + 0] = c.window_bits;
+    per_column[6 * i + 1] = c.num_windows;
+    per_column[6 * i + 2] = c.num_windows == 0 ? 0 : plan.tasks[c.first_task].num_slices;
+    per_column[6 * i + 3] = c.first_task;
+    per_column[6 * i + 4] = c.num_windows == 0 ? 0 : plan.tasks[c.first_task].slice_rows;
+    per_column[6 * i + 5] = c.num_windows == 0 ? 0 : plan.tasks[c.first_task].group_bits;
   }
   totals[0] = plan.tasks.size();
   totals[1] = plan.total_buckets;
@@ -180,7 +183,7 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
   u64 covered = 0;
   for (const auto& t : plan.tasks) covered += t.rows;
   totals[4] = covered;
-  totals[5] = plan.total_hist;
+  totals[5] = plan.total_groups;
 }
 
 // 9 x 29-bit field of the gfx950 kernels (field/f29.h); limbs in/out are raw u32[9]

@@ -150,23 +150,32 @@ def test_signed_digit_recoding_reconstructs_the_scalar():
 
 
 def test_planner_invariants():
-    ns = [0, 1, 97, 5000, 1 << 16, (1 << 16) + 1, 1 << 20, (1 << 20) + 3, 1 << 22]
-    widths = [256, 8, 32, 256, 64, 16, 256, 1, 256]
+    ns = [0, 1, 97, 5000, 1 << 16, (1 << 16) + 1, 1 << 20, (1 << 20) + 3, 1 << 22, 1 << 26,
+          (1 << 31) - 1]
+    widths = [256, 8, 32, 256, 64, 16, 256, 1, 256, 256, 128]
     per, totals = hooks.plan(ns, widths, [0] * len(ns))
     assert per[0].tolist()[:3] == [1, 0, 0]  # empty column: no tasks
-    covered = tasks = segs = hist = 0
-    for n, bw, (c, W, slices, first) in zip(ns, widths, per.tolist()):
+    covered = tasks = segs = part = 0
+    for n, bw, (c, W, slices, first, slice_rows, s) in zip(ns, widths, per.tolist()):
         if n == 0:
             continue
         assert first == tasks
         assert 2 <= c <= 16 and W * c >= bw + 1          # top digit never carries out
-        assert slices == (n + 65535) // 65536            # one sort workgroup per 64 Ki rows
+        # partition geometry of the two-pass sort: slices cover the rows, the 32-bit record
+        # sign | bucket-in-group (s bits) | row has room for every row index
+        assert slice_rows in (16384, 65536)
+        assert slices == (n + slice_rows - 1) // slice_rows
+        assert 0 <= s <= min(c - 1, 10) and n <= 1 << (31 - s)
+        groups = 1 << (c - 1 - s)
         covered += W * n
         tasks += W
         segs += W * ((n + 31) // 32)
-        hist += W * slices * (1 << (c - 1))
+        part += W * (groups + 1)
     assert int(totals[0]) == tasks and int(totals[4]) == covered
-    assert int(totals[3]) == segs and int(totals[5]) == hist
+    assert int(totals[3]) == segs and int(totals[5]) == part
+    # config 2 / config 3 shapes: groups of ~4096 entries, slices staged in LDS
+    per, _ = hooks.plan([1 << 20, 1 << 22], [256, 256], [0, 0])
+    assert per[0].tolist()[4:] == [16384, 7] and per[1].tolist()[4:] == [16384, 5]
     # signed columns are planned with c <= 15 by the engine (digits must fit int16 negated)
     per, _ = hooks.plan([1 << 20], [128], [1], max_window_bits=15)
     assert per[0][0] <= 15
