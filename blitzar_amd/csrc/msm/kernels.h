@@ -161,6 +161,13 @@ static __global__ void __launch_bounds__(256)
   if (tid == 0) gs[groups] = carry;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
+// memory counter (its release fence), which parks every wave until its fire-and-forget stores and
+// prefetched loads have come back; the sort kernels exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // the eight stored digits E = -D of one 16-byte vector
 __device__ __forceinline__ void unpack_digits(const uint4& pack, int e[8]) {
   const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
@@ -195,7 +202,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   u32* run_base = lds + 2 * groups + 1; // [groups]   Staged: where the run goes in `records`
   u32* staging = lds + 3 * groups + 1;  // [kStagedSliceRows]
   for (u32 g = tid; g < groups; g += kSortThreads) cursor[g] = 0;
-  __syncthreads();
+  lds_barrier();
   const u64 row0 = static_cast<u64>(slice) * task.slice_rows;
   const u32 rows =
       static_cast<u32>(task.rows - row0 < task.slice_rows ? task.rows - row0 : task.slice_rows);
@@ -217,7 +224,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       if (v * 8 + k < rows && e[k] != 0) atomicAdd(&cursor[(mag - 1) >> s], 1u);
     }
   }
-  __syncthreads();
+  lds_barrier();
   u32* cur = group_cursor + task.group_base;
   if constexpr (Staged) {
     // groups <= kSortThreads: one group per thread; exclusive scan of the counts
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       if (lane >= off) incl += up;
     }
     if (lane == 63) wave_sums[wave] = incl;
-    __syncthreads();
+    lds_barrier();
     u32 start = incl - count;
     for (u32 w = 0; w < wave; ++w) start += wave_sums[w];
     if (tid < groups) {
@@ -244,7 +251,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       cursor[g] = count != 0 ? atomicAdd(&cur[g], count) : 0;
     }
   }
-  __syncthreads();
+  lds_barrier();
   u32* out = records + task.entry_base;
   const u32 in_group = (1u << s) - 1, shift = 31 - s;
   for (u32 v = tid; v < nvec; v += kSortThreads) {
@@ -274,7 +281,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
     }
   }
   if constexpr (Staged) {
-    __syncthreads();
+    lds_barrier();
     for (u32 g = wave; g < groups; g += kSortThreads / 64) {
       const u32 from = local_start[g], count = local_start[g + 1] - from;
       u32* dst = out + run_base[g];
@@ -303,14 +310,14 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
   __shared__ u32 staging[kLocalSortCapacity];
   __shared__ u32 wave_sums[kGroupSortThreads / 64];
   const task_desc task = tasks[blockIdx.y];
-  const u32 g = blockIdx.x;
-  if (g >= task.num_groups) return;
   const u32 s = task.group_bits, buckets = 1u << s;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32* gs = group_start + task.group_base;
+  const u32 g = blockIdx.x;
+  if (g >= task.num_groups) return;
   const u32 begin = gs[g], total = gs[g + 1] - begin;
   for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
-  __syncthreads();
+  lds_barrier();
   const u32* rec = records + task.entry_base + begin;
   const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
   const bool staged = total <= kLocalSortCapacity; // uniform over the workgroup
@@ -330,7 +337,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       atomicAdd(&cursor[(rec[i] >> shift) & in_group], 1u);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // exclusive scan of the <= 2^kMaxGroupBits bucket counts, two adjacent buckets per lane
   const u32 b0 = 2 * tid;
   const u32 c0 = b0 < buckets ? cursor[b0] : 0, c1 = b0 + 1 < buckets ? cursor[b0 + 1] : 0;
@@ -342,7 +349,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
     if (lane >= off) incl += up;
   }
   if (lane == 63) wave_sums[wave] = incl;
-  __syncthreads();
+  lds_barrier();
   u32 start0 = incl - local;
   for (u32 w = 0; w < wave; ++w) start0 += wave_sums[w];
   const u32 start1 = start0 + c0;
@@ -355,7 +362,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
     cursor[b0 + 1] = start1;
     ends[b0 + 1] = begin + start1 + c1;
   }
-  __syncthreads();
+  lds_barrier();
   u32* out = sorted + task.entry_base + begin;
   u32* seg = segment_bucket + task.segment_base;
   if (staged) {
@@ -376,7 +383,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     for (u32 i = tid; i < total; i += kGroupSortThreads) out[i] = staging[i];
   } else {
     for (u32 i = tid; i < total; i += kGroupSortThreads) {
