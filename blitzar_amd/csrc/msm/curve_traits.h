@@ -96,6 +96,22 @@ struct ed25519_msm {
     }
     return ed16w::store_point(c, state);
   }
+  // v + m * s (m != 0) by a whole wavefront: every lane passes the same points and m
+  static constexpr bool has_wave_add_multiple = true;
+  __device__ static point wave_add_multiple(const point& v, const point& s, u32 m) {
+    __shared__ ed29_cached_packed addend[2];
+    const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
+    if (c.lane < 2) addend[c.lane] = ed29::pack(ed29::to_cached(c.lane == 0 ? s : v));
+    ed16w::wave_lds_sync();
+    const u32 sq = ed16w::load_words(c, addend[0].w), vq = ed16w::load_words(c, addend[1].w);
+    u32 state = ed16w::identity(c);
+    for (int bit = 31 - __builtin_clz(m); bit >= 0; --bit) {
+      state = ed16w::dbl(c, state);
+      if ((m >> bit) & 1) state = ed16w::add_cached(c, state, sq);
+    }
+    state = ed16w::add_cached(c, state, vq);
+    return ed16w::store_point(c, state);
+  }
   // canonical encoding by a whole wavefront (every lane passes the same point, lane 0 writes): the
   // inverse square root's 252 squarings run lane-parallel
   static constexpr bool has_wave_encode = true;
@@ -142,6 +158,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr size_t projective_size = sizeof(api_projective);
   static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
   static constexpr bool has_wave_encode = false;
+  static constexpr bool has_wave_add_multiple = false;
   // k_horner's dependent chain on one wavefront: doublings split over the lanes of each DPP quad
   // (curve/sw29_coop.h), the one addition per window computed redundantly by every lane
   static constexpr bool has_wave_horner = true;
