@@ -24,6 +24,7 @@ msm_context* msm_context_new() {
   auto* ctx = new msm_context();
   // development overrides of the sort geometry (plan.h)
   if (const char* v = std::getenv("BLITZAR_AMD_GROUP_ENTRIES")) ctx->tuning.partition_group_entries = std::strtoul(v, nullptr, 10);
+  if (const char* v = std::getenv("BLITZAR_AMD_MAX_WINDOW_BITS")) ctx->tuning.max_window_bits = std::strtoul(v, nullptr, 10);
   return ctx;
 }
 void msm_context_free(msm_context* ctx) { delete ctx; }

@@ -106,7 +106,9 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   if (needs_addends) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
   need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
   need += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
-  need += 2 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
+  need += 3 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
+  need += device_arena::padded(sizeof(u32) * (num_tasks + 1));
+  need += device_arena::padded(sizeof(u32) * 2 * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
   need += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
@@ -203,6 +205,9 @@ template <class C> struct batch_buffers {
   u32* sorted;
   u32* group_cursor;
   u32* group_start;
+  u32* group_chunk;
+  u32* big_tasks;    // [0] = count, then the tasks that have oversized groups
+  u32* bucket_count; // [2][total_buckets + 1]: histograms and fill cursors of oversized groups
   u32* segment_bucket;
   u32* bucket_end;
   typename C::point* bucket_sums;
@@ -261,6 +266,9 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.sorted = ctx.arena.take<u32>(plan.total_entries + 8);
   b.group_cursor = ctx.arena.take<u32>(plan.total_groups + 1);
   b.group_start = ctx.arena.take<u32>(plan.total_groups + 1);
+  b.group_chunk = ctx.arena.take<u32>(plan.total_groups + 1);
+  b.big_tasks = ctx.arena.take<u32>(num_tasks + 1);
+  b.bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
   b.segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
   b.bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
   b.bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
@@ -286,9 +294,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   BZ_HIP_CHECK(hipMemsetAsync(b.group_cursor, 0, sizeof(u32) * (plan.total_groups + 1), stream));
   ctx.timer.timed(timing, 2, stream, [&] {
     hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       part_lds, stream, b.group_cursor, b.digits, b.tasks);
+                       part_lds, stream, b.group_cursor, b.big_tasks, b.digits, b.tasks);
+    u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
     hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, stream, b.group_cursor,
-                       b.group_start, b.tasks);
+                       b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
+                       b.tasks);
     // all tasks of a launch share one variant: staged unless some column needs the direct form
     if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
       const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
@@ -300,9 +310,16 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                          dim3(kSortThreads), part_lds, stream, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
-    hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads), 0,
-                       stream, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
-                       b.tasks);
+    hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads),
+                       0, stream, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                       b.group_chunk, b.tasks);
+    // oversized groups (skewed digits); both launches find nothing to do on uniform data
+    hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, stream,
+                       b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,
+                       b.big_tasks);
+    hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, stream,
+                       b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
+                       b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
   });
   ctx.timer.timed(timing, 3, stream, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
@@ -321,7 +338,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        b.partial_stride, b.cols, b.tasks, b.bucket_end, 0u, 0xffffffffu, 1, 1);
   });
   if (timing) ctx.timer.calls += 1;
-  g_kernel_launches += 8;
+  g_kernel_launches += 10;
   BZ_HIP_CHECK(hipGetLastError());
 }
 

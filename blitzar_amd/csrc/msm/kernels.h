@@ -9,8 +9,8 @@
 //   k_group_hist       per (task, slice of rows): LDS histogram of the digits by bucket *group*
 //   k_group_offsets    per task: exclusive scan of the group totals -> start of every group
 //   k_group_scatter    per (task, slice): partition the digits into per-group runs of records
-//   k_group_sort       per (task, group): counting sort of the group by bucket inside LDS ->
-//                      `row | sign << 31` list, bucket end offsets, segment -> bucket map
+//   k_group_sort       per (task, group; k_group_big_*: chunk of an oversized group): counting sort by bucket inside
+//                      LDS -> `row | sign << 31` list, bucket end offsets, segment -> bucket map
 //                      (together a two-pass radix sort by bucket; reference K1/K2:
 //                       bucket_method2/multiproduct_table_kernel.h:32-93, multiproduct_table.cc:74-82)
 //   k_accumulate       one lane per 32 consecutive *sorted entries* (not per bucket): gather
@@ -36,6 +36,8 @@ namespace bz {
 using i16 = int16_t;
 
 constexpr u32 kSortThreads = 1024;
+constexpr u32 kReduceHeavyHeads = 16; // k_reduce folds buckets with more head partials cooperatively
+constexpr u32 kReduceMaxHeavy = 8;    // ... up to this many per workgroup (the rest stay with their lane)
 constexpr u32 kAccumulateThreads = 256;
 constexpr u32 kCombineThreads = 256;
 
@@ -101,9 +103,10 @@ __device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig
 // Pass 1a.  group_total[task.group_base + g] += digits of the slice whose bucket lies in group g
 // (2^s consecutive buckets): LDS histogram, one global atomic per populated group.
 static __global__ void __launch_bounds__(kSortThreads)
-    k_group_hist(u32* __restrict__ group_total, const i16* __restrict__ digits,
-                 const task_desc* __restrict__ tasks) {
+    k_group_hist(u32* __restrict__ group_total, u32* __restrict__ big_tasks,
+                 const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) big_tasks[0] = 0; // k_group_offsets appends
   const task_desc task = tasks[blockIdx.y];
   const u32 slice = blockIdx.x;
   if (slice >= task.num_slices) return;
@@ -125,40 +128,79 @@ static __global__ void __launch_bounds__(kSortThreads)
   }
 }
 
-// Pass 1b, one workgroup per task: exclusive scan of the group totals.
+// chunks an oversized group of `total` records is cut into in pass 2 (0: one workgroup sorts it)
+constexpr u32 kStreamedSortRecords = 16 * kLocalSortCapacity;
+__device__ __forceinline__ u32 big_chunks_of(u32 total) {
+  return total <= kStreamedSortRecords ? 0 : (total + kLocalSortCapacity - 1) / kLocalSortCapacity;
+}
+
+// Pass 1b, one workgroup per task: exclusive scans over the groups.
 //   group_start[task.group_base + g] = first record of group g, entry [G] = records of the task;
-//   group_cursor (the totals, in place) = the same offsets, bumped by k_group_scatter.
+//   group_cursor (the totals, in place) = the same offsets, bumped by k_group_scatter;
+//   group_chunk[task.group_base + g] = chunks of the oversized groups before g, entry [G] = their
+//   number (all zero on uniform digits); the bucket counters of oversized groups are cleared and
+//   the task is appended to big_tasks.
 static __global__ void __launch_bounds__(256)
     k_group_offsets(u32* __restrict__ group_cursor, u32* __restrict__ group_start,
+                    u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
+                    u32* __restrict__ bucket_fill, u32* __restrict__ big_tasks,
                     const task_desc* __restrict__ tasks) {
   __shared__ u32 wave_sums[4];
+  __shared__ u32 wave_chunks[4];
   const task_desc task = tasks[blockIdx.x];
   const u32 groups = task.num_groups;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   u32* cur = group_cursor + task.group_base;
   u32* gs = group_start + task.group_base;
-  u32 carry = 0;
+  u32* gc = group_chunk + task.group_base;
+  u32 carry = 0, chunk_carry = 0;
   for (u32 g0 = 0; g0 < groups; g0 += 256) {
     const u32 g = g0 + tid;
     const u32 total = g < groups ? cur[g] : 0;
-    u32 incl = total;
+    const u32 chunks = g < groups ? big_chunks_of(total) : 0;
+    u32 incl = total, chunk_incl = chunks;
 #pragma unroll
     for (u32 off = 1; off < 64; off <<= 1) {
       const u32 up = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += up;
+      const u32 chunk_up = __shfl_up(chunk_incl, off, 64);
+      if (lane >= off) {
+        incl += up;
+        chunk_incl += chunk_up;
+      }
     }
-    __syncthreads(); // wave_sums of the previous round have been read
-    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads(); // the sums of the previous round have been read
+    if (lane == 63) {
+      wave_sums[wave] = incl;
+      wave_chunks[wave] = chunk_incl;
+    }
     __syncthreads();
-    u32 base = carry;
-    for (u32 w = 0; w < wave; ++w) base += wave_sums[w];
+    u32 base = carry, chunk_base = chunk_carry;
+    for (u32 w = 0; w < wave; ++w) {
+      base += wave_sums[w];
+      chunk_base += wave_chunks[w];
+    }
     if (g < groups) {
       gs[g] = base + incl - total;
       cur[g] = base + incl - total;
+      gc[g] = chunk_base + chunk_incl - chunks;
+      if (chunks != 0) {
+        // an oversized group: its chunks meet in these counters (k_group_big_hist / _sort)
+        const u64 first = task.bucket_base + (static_cast<u64>(g) << task.group_bits);
+        for (u32 b = 0; b < (1u << task.group_bits); ++b) {
+          bucket_count[first + b] = 0;
+          bucket_fill[first + b] = 0;
+        }
+      }
     }
     carry += wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    chunk_carry += wave_chunks[0] + wave_chunks[1] + wave_chunks[2] + wave_chunks[3];
   }
-  if (tid == 0) gs[groups] = carry;
+  if (tid == 0) {
+    gs[groups] = carry;
+    gc[groups] = chunk_carry;
+    // big_tasks[0] = number of tasks with oversized groups (zeroed by the host), then their indices
+    if (chunk_carry != 0) big_tasks[1 + atomicAdd(&big_tasks[0], 1u)] = blockIdx.x;
+  }
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
@@ -290,31 +332,46 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   }
 }
 
-// Pass 2, one workgroup per (task, group): counting sort of the group's records by bucket.
+// Pass 2: counting sort of every group's records by bucket.
 //   sorted[task.entry_base + pos] = row | (digit negative) << 31, grouped by bucket;
 //   bucket_end[task.bucket_base + b] = end offset of bucket b in the task's sorted list;
 //   segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment.
-// A group of at most kLocalSortCapacity records (the normal case) is held in registers, its piece
-// of the sorted list assembled in LDS and written out in order (coalesced); a larger group
-// (skewed digits, very long columns) streams its records twice and writes its piece directly.
+// k_group_sort, one workgroup per (task, group): a group of at most kLocalSortCapacity records
+// (nearly every group, on uniform digits) is held in registers, count -> scan -> rank run in LDS, the
+// group's piece of the sorted list is assembled in LDS and written out in order (coalesced).
+// Up to 16 times that (a window whose digits use few of its buckets, like the top one) the
+// workgroup streams its records twice and writes its piece directly.
+// A larger group still (skewed digits: constants, booleans; very long columns) is cut into chunks of
+// kLocalSortCapacity records that cooperate through global memory, in two small launches whose
+// workgroups loop over the chunks (nothing to do on uniform digits):
+//   k_group_big_hist  adds every chunk's bucket histogram into bucket_count,
+//   k_group_big_sort  scans the group's bucket counts, claims a run per (chunk, bucket) with an
+//                     atomic on bucket_fill, sorts the chunk in LDS and copies the runs out.
+// Equal keys of a wavefront are combined before they touch an LDS counter (wave_aggregated_add):
+// on skewed data all 64 lanes hit the same counter, which would serialise them.
 constexpr u32 kGroupSortThreads = 512;
 constexpr u32 kLocalSortPerThread = kLocalSortCapacity / kGroupSortThreads;
+constexpr u32 kBigSortBlocks = 128; // grid of the two oversized-group launches (their workgroups
+                                    // loop; even empty ones cost ~35 ns each to dispatch)
 static_assert(kLocalSortPerThread * kGroupSortThreads == kLocalSortCapacity);
 static_assert(2 * kGroupSortThreads >= (1u << kMaxGroupBits));
 
 static __global__ void __launch_bounds__(kGroupSortThreads)
     k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
                  u32* __restrict__ bucket_end, const u32* __restrict__ records,
-                 const u32* __restrict__ group_start, const task_desc* __restrict__ tasks) {
+                 const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                 const task_desc* __restrict__ tasks) {
   __shared__ u32 cursor[1u << kMaxGroupBits];
   __shared__ u32 staging[kLocalSortCapacity];
   __shared__ u32 wave_sums[kGroupSortThreads / 64];
   const task_desc task = tasks[blockIdx.y];
+  const u32 g = blockIdx.x;
+  if (g >= task.num_groups) return;
+  const u32* gc = group_chunk + task.group_base;
+  if (gc[g + 1] != gc[g]) return; // oversized: k_group_big_hist / k_group_big_sort
   const u32 s = task.group_bits, buckets = 1u << s;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32* gs = group_start + task.group_base;
-  const u32 g = blockIdx.x;
-  if (g >= task.num_groups) return;
   const u32 begin = gs[g], total = gs[g + 1] - begin;
   for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
   lds_barrier();
@@ -333,8 +390,20 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       if (tid + k * kGroupSortThreads < total) atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
     }
   } else {
-    for (u32 i = tid; i < total; i += kGroupSortThreads) {
-      atomicAdd(&cursor[(rec[i] >> shift) & in_group], 1u);
+    // up to kStreamedSortRecords records (a window whose digits use few of its buckets): streamed
+    // twice, kLocalSortCapacity at a time
+    for (u32 base = 0; base < total; base += kLocalSortCapacity) {
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        const u32 i = base + tid + k * kGroupSortThreads;
+        mine[k] = i < total ? rec[i] : 0;
+      }
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        if (base + tid + k * kGroupSortThreads < total) {
+          atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        }
+      }
     }
   }
   lds_barrier();
@@ -365,8 +434,8 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
   lds_barrier();
   u32* out = sorted + task.entry_base + begin;
   u32* seg = segment_bucket + task.segment_base;
+  u32 pos[kLocalSortPerThread];
   if (staged) {
-    u32 pos[kLocalSortPerThread];
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
       pos[k] = 0;
@@ -386,13 +455,226 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
     lds_barrier();
     for (u32 i = tid; i < total; i += kGroupSortThreads) out[i] = staging[i];
   } else {
-    for (u32 i = tid; i < total; i += kGroupSortThreads) {
-      const u32 r = rec[i];
-      const u32 b = (r >> shift) & in_group;
-      const u32 pos = atomicAdd(&cursor[b], 1u);
-      out[pos] = (r & 0x80000000u) | (r & row_mask);
-      if ((begin + pos) % kSegmentEntries == 0) seg[(begin + pos) / kSegmentEntries] = (g << s) + b;
+    for (u32 base = 0; base < total; base += kLocalSortCapacity) {
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        const u32 i = base + tid + k * kGroupSortThreads;
+        mine[k] = i < total ? rec[i] : 0;
+      }
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        pos[k] = 0;
+        if (base + tid + k * kGroupSortThreads < total) {
+          pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        }
+      }
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        if (base + tid + k * kGroupSortThreads < total) {
+          out[pos[k]] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
+          if ((begin + pos[k]) % kSegmentEntries == 0) {
+            seg[(begin + pos[k]) / kSegmentEntries] = (g << s) + ((mine[k] >> shift) & in_group);
+          }
+        }
+      }
     }
+  }
+}
+
+// The oversized group that chunk `index` (counted over all oversized groups of the task) belongs
+// to: the largest g with chunk_first[g] <= index; groups that fit one workgroup repeat the value
+// of their successor, so the search lands on an oversized one.
+__device__ __forceinline__ u32 locate_big_group(const u32* __restrict__ chunk_first, u32 groups,
+                                                u32 index) {
+  u32 lo = 0, hi = groups;
+  while (hi - lo > 1) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if (chunk_first[mid] <= index) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
+}
+
+// counters[key] += 1 for every active lane, returning what the lane's own atomicAdd(..., 1) would
+// have: keys shared by many lanes of the wavefront (the heavy hitters of skewed data, which would
+// serialise 64 lanes on one LDS counter) are combined into one atomic per key, up to three keys;
+// the remaining lanes -- all of them when the keys are spread -- use their own atomic.
+__device__ __forceinline__ u32 wave_aggregated_add(u32* counters, u32 key, bool active) {
+  const u32 lane = threadIdx.x & 63;
+  u32 result = 0;
+  unsigned long long todo = __ballot(active);
+  for (int round = 0; round < 3 && todo != 0; ++round) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const u32 leader_key = __shfl(key, leader, 64);
+    const unsigned long long same = __ballot(active && key == leader_key) & todo;
+    if (__popcll(same) < 8) break;
+    u32 base = 0;
+    if (static_cast<int>(lane) == leader) {
+      base = atomicAdd(&counters[leader_key], static_cast<u32>(__popcll(same)));
+    }
+    base = __shfl(base, leader, 64);
+    if ((same >> lane) & 1) {
+      result = base + static_cast<u32>(__popcll(same & ((1ull << lane) - 1)));
+    }
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1) result = atomicAdd(&counters[key], 1u);
+  return result;
+}
+
+static __global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_big_hist(u32* __restrict__ bucket_count, const u32* __restrict__ records,
+                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
+  __shared__ u32 cursor[1u << kMaxGroupBits];
+  const u32 num_big_tasks = big_tasks[0];
+  for (u32 t = 0; t < num_big_tasks; ++t) {
+  const task_desc task = tasks[big_tasks[1 + t]];
+  const u32* gc = group_chunk + task.group_base;
+  const u32 big_chunks = gc[task.num_groups];
+  const u32 s = task.group_bits, buckets = 1u << s;
+  const u32 tid = threadIdx.x;
+  const u32 in_group = buckets - 1, shift = 31 - s;
+  const u32* gs = group_start + task.group_base;
+  // every workgroup of the launch takes chunks of every listed task, starting at a different one
+  for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
+    const u32 g = locate_big_group(gc, task.num_groups, index);
+    const u32 begin = gs[g] + (index - gc[g]) * kLocalSortCapacity;
+    const u32 total = gs[g + 1] - begin < kLocalSortCapacity ? gs[g + 1] - begin : kLocalSortCapacity;
+    for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
+    lds_barrier();
+    const u32* rec = records + task.entry_base + begin;
+    u32 mine[kLocalSortPerThread];
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      const u32 i = tid + k * kGroupSortThreads;
+      mine[k] = i < total ? rec[i] : 0;
+    }
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      wave_aggregated_add(cursor, (mine[k] >> shift) & in_group, tid + k * kGroupSortThreads < total);
+    }
+    lds_barrier();
+    u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
+    for (u32 b = tid; b < buckets; b += kGroupSortThreads) {
+      if (cursor[b] != 0) atomicAdd(&counts[b], cursor[b]);
+    }
+    lds_barrier(); // cursor is reused by the next chunk
+  }
+  }
+}
+
+static __global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_big_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                     u32* __restrict__ bucket_end, const u32* __restrict__ bucket_count,
+                     u32* __restrict__ bucket_fill, const u32* __restrict__ records,
+                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
+  constexpr u32 kBuckets = 1u << kMaxGroupBits;
+  __shared__ u32 run_base[kBuckets];    // where this chunk's run of the bucket goes (group-relative)
+  __shared__ u32 local_start[kBuckets]; // first staged entry of the bucket
+  __shared__ u32 cursor[kBuckets];
+  __shared__ u32 staging[kLocalSortCapacity];
+  __shared__ unsigned short staged_bucket[kLocalSortCapacity];
+  __shared__ u32 wave_sums[kGroupSortThreads / 64];
+  const u32 num_big_tasks = big_tasks[0];
+  for (u32 t = 0; t < num_big_tasks; ++t) {
+  const task_desc task = tasks[big_tasks[1 + t]];
+  const u32* gc = group_chunk + task.group_base;
+  const u32 big_chunks = gc[task.num_groups];
+  const u32 s = task.group_bits, buckets = 1u << s;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32* gs = group_start + task.group_base;
+  const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
+  // block-wide exclusive scan of two adjacent values per lane (b0 = 2 tid)
+  const u32 b0 = 2 * tid;
+  auto scan_pairs = [&](u32 v0, u32 v1, u32& start0, u32& start1) {
+    const u32 local = v0 + v1;
+    u32 incl = local;
+#pragma unroll
+    for (u32 off = 1; off < 64; off <<= 1) {
+      const u32 up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    lds_barrier(); // wave_sums of an earlier scan have been read
+    if (lane == 63) wave_sums[wave] = incl;
+    lds_barrier();
+    start0 = incl - local;
+    for (u32 w = 0; w < wave; ++w) start0 += wave_sums[w];
+    start1 = start0 + v0;
+  };
+  for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
+    const u32 g = locate_big_group(gc, task.num_groups, index);
+    const u32 chunk = index - gc[g];
+    const u32 group_begin = gs[g], group_end = gs[g + 1];
+    const u32 begin = group_begin + chunk * kLocalSortCapacity;
+    const u32 total = group_end - begin < kLocalSortCapacity ? group_end - begin : kLocalSortCapacity;
+    const u32* rec = records + task.entry_base + begin;
+    u32 mine[kLocalSortPerThread];
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      const u32 i = tid + k * kGroupSortThreads;
+      mine[k] = i < total ? rec[i] : 0;
+    }
+    // the group's bucket starts from the global histogram
+    const u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
+    const u32 g0 = b0 < buckets ? counts[b0] : 0, g1 = b0 + 1 < buckets ? counts[b0 + 1] : 0;
+    u32 gstart0, gstart1;
+    scan_pairs(g0, g1, gstart0, gstart1);
+    if (chunk == 0) {
+      u32* ends = bucket_end + task.bucket_base + (static_cast<u64>(g) << s);
+      if (b0 < buckets) ends[b0] = group_begin + gstart0 + g0;
+      if (b0 + 1 < buckets) ends[b0 + 1] = group_begin + gstart1 + g1;
+    }
+    // the chunk's own histogram
+    for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
+    lds_barrier();
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      wave_aggregated_add(cursor, (mine[k] >> shift) & in_group, tid + k * kGroupSortThreads < total);
+    }
+    lds_barrier();
+    const u32 c0 = b0 < buckets ? cursor[b0] : 0, c1 = b0 + 1 < buckets ? cursor[b0 + 1] : 0;
+    u32 lstart0, lstart1;
+    scan_pairs(c0, c1, lstart0, lstart1);
+    u32* fill = bucket_fill + task.bucket_base + (static_cast<u64>(g) << s);
+    if (b0 < buckets) {
+      local_start[b0] = lstart0;
+      cursor[b0] = lstart0;
+      run_base[b0] = gstart0 + (c0 != 0 ? atomicAdd(&fill[b0], c0) : 0);
+    }
+    if (b0 + 1 < buckets) {
+      local_start[b0 + 1] = lstart1;
+      cursor[b0 + 1] = lstart1;
+      run_base[b0 + 1] = gstart1 + (c1 != 0 ? atomicAdd(&fill[b0 + 1], c1) : 0);
+    }
+    lds_barrier();
+#pragma unroll
+    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      const bool active = tid + k * kGroupSortThreads < total;
+      const u32 b = (mine[k] >> shift) & in_group;
+      const u32 pos = wave_aggregated_add(cursor, b, active);
+      if (active) {
+        staging[pos] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
+        staged_bucket[pos] = static_cast<unsigned short>(b);
+      }
+    }
+    lds_barrier();
+    u32* out = sorted + task.entry_base + group_begin;
+    u32* seg = segment_bucket + task.segment_base;
+    for (u32 i = tid; i < total; i += kGroupSortThreads) {
+      const u32 b = staged_bucket[i];
+      const u32 at = run_base[b] + (i - local_start[b]); // group-relative position
+      out[at] = staging[i];
+      if ((group_begin + at) % kSegmentEntries == 0) {
+        seg[(group_begin + at) / kSegmentEntries] = (g << s) + b;
+      }
+    }
+    lds_barrier(); // the LDS arrays are reused by the next chunk
+  }
   }
 }
 
@@ -513,6 +795,29 @@ load_bucket(const typename C::point* __restrict__ sums, const typename C::point*
   return v;
 }
 
+// The head partials load_bucket visits for a bucket covering sorted entries [begin, end), in
+// closed form: segment first + 1, every multiple of 64 strictly between that and the last whole
+// segment boundary, and the trailing partial segment.
+struct bucket_heads {
+  u32 s0, k_lo, middle, tail_index, count; // indices: s0 | (k_lo + j) * 64, j < middle | tail_index
+  __device__ __forceinline__ u32 index(u32 j) const {
+    return j == 0 ? s0 : (j <= middle ? (k_lo + j - 1) * 64 : tail_index);
+  }
+};
+__device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end) {
+  const u32 first = begin / kSegmentEntries, last = (end - 1) / kSegmentEntries;
+  const u32 after_whole = end / kSegmentEntries;
+  bucket_heads h;
+  h.s0 = first + 1;
+  h.k_lo = h.s0 / 64 + 1;
+  const u32 k_hi_plus_1 = (after_whole + 63) / 64; // multiples 64 k with s0 < 64 k < after_whole
+  h.middle = k_hi_plus_1 > h.k_lo ? k_hi_plus_1 - h.k_lo : 0;
+  h.tail_index = after_whole;
+  const u32 tail = after_whole <= last && after_whole > h.s0 ? 1 : 0;
+  h.count = h.s0 > last ? 0 : 1 + h.middle + tail;
+  return h;
+}
+
 //--------------------------------------------------------------------------------------------------
 // k_reduce
 //--------------------------------------------------------------------------------------------------
@@ -550,6 +855,50 @@ __global__ void __launch_bounds__(kReduceThreads)
     return;
   }
   const u32 seg_first = block_first + tid * kReduceSegment;
+  const point* bs = bucket_sums + task.bucket_base;
+  const point* hd = heads + task.segment_base;
+  // Heavy buckets first.  A bucket that holds a large share of a skewed column (constants,
+  // booleans) spans thousands of segments and leaves one head partial per 64 of them: its owner
+  // lane would add them one after the other (2^20 equal scalars: 512 dependent additions, 2 ms).
+  // The workgroup folds such buckets cooperatively -- the heads dealt out over the 256 lanes, an
+  // LDS tree on top -- and phase 1 picks the finished sums up from LDS.
+  __shared__ u32 heavy_bucket[kReduceMaxHeavy];
+  __shared__ u32 heavy_count;
+  __shared__ point heavy_sum[kReduceMaxHeavy];
+  if (tid == 0) heavy_count = 0;
+  __syncthreads();
+  if (seg_first < nb) {
+    const u32 seg_last = seg_first + kReduceSegment < nb ? seg_first + kReduceSegment : nb;
+    u32 begin = seg_first == 0 ? 0 : ends[seg_first - 1];
+    for (u32 b = seg_first; b < seg_last; ++b) {
+      const u32 end = ends[b];
+      if (end != begin && heads_of(begin, end).count > kReduceHeavyHeads) {
+        const u32 slot = atomicAdd(&heavy_count, 1u);
+        if (slot < kReduceMaxHeavy) heavy_bucket[slot] = b;
+      }
+      begin = end;
+    }
+  }
+  __syncthreads();
+  const u32 num_heavy = heavy_count < kReduceMaxHeavy ? heavy_count : kReduceMaxHeavy;
+  for (u32 h = 0; h < num_heavy; ++h) {
+    const u32 b = heavy_bucket[h];
+    const bucket_heads list = heads_of(b == 0 ? 0 : ends[b - 1], ends[b]);
+    point part = C::identity();
+    bool any = false;
+    for (u32 j = tid; j < list.count; j += kReduceThreads) {
+      part = any ? C::add(part, hd[list.index(j)]) : hd[list.index(j)];
+      any = true;
+    }
+    tree[tid] = part;
+    __syncthreads();
+    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+      if (tid < stride && tid + stride < list.count) tree[tid] = C::add(tree[tid], tree[tid + stride]);
+      __syncthreads();
+    }
+    if (tid == 0) heavy_sum[h] = C::add(tree[0], bs[b]);
+    __syncthreads();
+  }
   point s = C::identity();
   point r = C::identity();
   bool populated = false;
@@ -559,12 +908,17 @@ __global__ void __launch_bounds__(kReduceThreads)
     const u32 hi = ends[seg_last - 1];
     if (hi != lo) {
       populated = true;
-      const point* bs = bucket_sums + task.bucket_base;
-      const point* hd = heads + task.segment_base;
       u32 end = hi;
       for (u32 b = seg_last; b-- > seg_first;) {
         const u32 begin = b == 0 ? 0 : ends[b - 1];
-        if (begin != end) s = C::add(s, load_bucket<C>(bs, hd, begin, end, b));
+        if (begin != end) {
+          u32 folded = kReduceMaxHeavy;
+          if (num_heavy != 0 && heads_of(begin, end).count > kReduceHeavyHeads) {
+            for (u32 h = 0; h < num_heavy; ++h) folded = heavy_bucket[h] == b ? h : folded;
+          }
+          s = C::add(s, folded < kReduceMaxHeavy ? heavy_sum[folded]
+                                                 : load_bucket<C>(bs, hd, begin, end, b));
+        }
         r = C::add(r, s);
         end = begin;
       }

@@ -289,6 +289,30 @@ def test_skewed_long_column(gpu_backend):
     assert np.array_equal(hooks.ristretto_encode(acc), out[0])
 
 
+def test_skewed_long_columns_match_oracle(gpu_backend, oracle):
+    """2^17 rows of the shapes table columns have -- all ones, booleans, two distinct 128-bit
+    values, 10-bit integers, a mostly-zero column: bucket groups far beyond what one workgroup
+    sorts, split into cooperating chunks (k_group_sort_big), and heavy buckets folded by whole
+    workgroups in k_reduce"""
+    api = gpu_backend
+    rng = np.random.default_rng(11)
+    n = 1 << 17
+    gens = util.generators_for(0, n)
+    g = util.api_generators(0, gens)
+    two = rng.integers(0, 256, (2, 16), dtype=np.uint8)
+    small = np.zeros((n, 8), np.uint8)
+    small[:, :2] = rng.integers(0, 256, (n, 2))
+    small[:, 1] &= 0x03
+    sparse = np.zeros((n, 16), np.uint8)
+    hits = rng.integers(0, n, n // 10)
+    sparse[hits] = rng.integers(0, 256, (hits.size, 16), dtype=np.uint8)
+    cols = [(np.ones((n, 1), np.uint8), False), (rng.integers(0, 2, (n, 1), dtype=np.uint8), False),
+            (two[rng.integers(0, 2, n)], False), (small, False), (sparse, False),
+            (np.full((n, 2), 0xff, np.uint8), True)]
+    want = oracle.commit(0, cols, gens)
+    assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
+
+
 def test_device_resident_entry_points(gpu_backend, oracle):
     """include/blitzar_amd.h: operands already in HBM (torch tensors only provide the memory),
     resident generator sets reused across calls, caller-provided stream"""
