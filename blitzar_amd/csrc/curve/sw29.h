@@ -77,20 +77,24 @@ template <class P> struct sw29 {
                             const fe& u3) {
     const pm s = plus_minus(t1, u2);
     point r;
+    // every coordinate is a sum of two products: one Montgomery reduction each (F::mul2)
     if constexpr (!P::b3_negative) {
       // z3 = t1 + 3b Z, t1' = t1 - 3b Z, y3 = 3b (...)
-      const fe& z3 = s.plus;
-      const fe& t1m = s.minus;
-      r.X = F::norm(F::template sub<4>(F::mul(t3, t1m), F::mul(t4, u3)));   // V < 5.4
-      r.Y = F::norm(F::add(F::mul(t1m, z3), F::mul(u3, t0)));               // V < 2.4
-      r.Z = F::norm(F::add(F::mul(z3, t4), F::mul(t0, t3)));                // V < 2.4
+      const fe z3 = F::norm(s.plus);                              // B 1, V < 5.3
+      const fe& t1m = s.minus;                                    // B 1, V < 9.3
+      const fe t4n = F::template neg<8>(t4);                      // B <= 3, V < 8
+      r.X = F::mul2(t3, t1m, t4n, u3);                            // B 1*1 + 3*1, V 55 + 32
+      r.Y = F::mul2(t1m, z3, u3, t0);                             // B 1*1 + 1*3
+      r.Z = F::mul2(z3, t4, t0, t3);                              // B 1*2 + 3*1
     } else {
       // 3b = -|3b|: z3 = t1 - u2, t1' = t1 + u2, y3 = -u3
-      const fe& z3 = s.minus;
-      const fe& t1m = s.plus;
-      r.X = F::norm(F::add(F::mul(t3, t1m), F::mul(t4, u3)));               // V < 2.4
-      r.Y = F::norm(F::template sub<4>(F::mul(t1m, z3), F::mul(u3, t0)));   // V < 5.4
-      r.Z = F::norm(F::add(F::mul(z3, t4), F::mul(t0, t3)));                // V < 2.4
+      const fe& z3 = s.minus;                                     // B 1, V < 9.3
+      const fe& t1m = s.plus;                                     // B 2, V < 5.3
+      const fe t0r = F::norm(t0);                                 // B 1, V < 3.7
+      const fe t0n = F::template neg<4>(t0r);                     // B <= 3, V < 4
+      r.X = F::mul2(t3, t1m, t4, u3);                             // B 1*2 + 2*1
+      r.Y = F::mul2(t1m, z3, u3, t0n);                            // B 2*1 + 1*3
+      r.Z = F::mul2(z3, t4, t0r, t3);                             // B 1*2 + 1*1
     }
     return r;
   }
@@ -133,11 +137,10 @@ template <class P> struct sw29 {
     point r;
     r.Z = F::mul(t1, z3);                                                    // V < 1.1
     if constexpr (!P::b3_negative) {
-      const fe x3 = F::mul(u, z3);
       const fe y3 = F::add(t0, u);                                           // B 2, V < 5.3
       const fe u3 = F::norm(F::add(F::add(u, u), u));                        // V < 12
       const fe t0m = F::norm(F::template sub<16>(t0, u3));                   // V < 17.3
-      r.Y = F::norm(F::add(x3, F::mul(t0m, y3)));                            // V < 2.8
+      r.Y = F::mul2(u, z3, t0m, y3);                                         // B 1*1 + 1*2, V < 1.8
       const fe x = F::mul(t0m, xy);
       r.X = F::norm(F::add(x, x));                                           // V < 2.3
     } else {

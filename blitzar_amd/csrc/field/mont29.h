@@ -20,6 +20,7 @@
 //   mul(a, b):   N (B_a B_b + 1) <= 64  (i.e. B_a B_b <= 6 for N = 9, <= 3.5 for N = 14);
 //                V_a V_b <= max_v^2-ish such that the result fits; result normalised,
 //                V < V_a V_b / max_v + 1
+//   mul2(a,b,c,d): a b + c d with one reduction; N (B_a B_b + B_c B_d + 1) <= 2^(64 - 2 LB)
 //   add(a, b):   limb-wise (B and V add up)
 //   sub<K>(a,b): a + K p - b with the limbs of K p inflated; needs every limb of b <= 2^(LB+1) - 2
 //                and V_b < K - 0.01; result B <= B_a + 3, V < V_a + K
@@ -144,6 +145,19 @@ template <class P> struct mont29 {
         static_cast<unsigned __int128>(N) * (u64{1} << LB) * (u64{1} << LB) + (u64{1} << 40);
     BZ_M29_ASSERT(worst < (static_cast<unsigned __int128>(1) << 64), "mul: column accumulator overflow");
   }
+  static void check_mul2_operands(const fe& a, const fe& b, const fe& c, const fe& d) {
+    u64 ma = 0, mb = 0, mc = 0, md = 0;
+    for (int i = 0; i < N; ++i) {
+      if (a.v[i] > ma) ma = a.v[i];
+      if (b.v[i] > mb) mb = b.v[i];
+      if (c.v[i] > mc) mc = c.v[i];
+      if (d.v[i] > md) md = d.v[i];
+    }
+    const unsigned __int128 worst =
+        static_cast<unsigned __int128>(N) * ma * mb + static_cast<unsigned __int128>(N) * mc * md +
+        static_cast<unsigned __int128>(N) * (u64{1} << LB) * (u64{1} << LB) + (u64{1} << 40);
+    BZ_M29_ASSERT(worst < (static_cast<unsigned __int128>(1) << 64), "mul2: column accumulator overflow");
+  }
 #endif
 
   // Montgomery product a b / R (mod p), coarsely integrated operand scanning on 64-bit column
@@ -182,6 +196,42 @@ template <class P> struct mont29 {
   }
 
   BZ_HD static fe sqr(const fe& a) { return mul(a, a); }
+
+  // (a b + c d) / R (mod p) with ONE Montgomery reduction: the two products share the column
+  // accumulators, so the sum costs 3 N^2 mads instead of the 4 N^2 of two products.  Contract:
+  // N (B_a B_b + B_c B_d + 1) <= 2^(64 - 2 LB); result normalised, V < (V_a V_b + V_c V_d) / max_v + 1.
+  BZ_HD static fe mul2(const fe& a, const fe& b, const fe& c, const fe& d) {
+#if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    check_mul2_operands(a, b, c, d);
+#endif
+    u64 t[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) t[j] = mad(a.v[j], b.v[i], t[j]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) t[j] = mad(c.v[j], d.v[i], t[j]);
+      const u32 m = (static_cast<u32>(t[0]) * P::inv) & kMask;
+#pragma unroll
+      for (int j = 0; j < N; ++j) t[j] = mad(m, P::p(j), t[j]);
+      const u64 carry = t[0] >> LB;
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) t[j] = t[j + 1];
+      t[0] += carry;
+      t[N - 1] = 0;
+    }
+    fe h;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      h.v[j] = static_cast<u32>(t[j]) & kMask;
+      t[j + 1] += t[j] >> LB;
+    }
+    BZ_M29_ASSERT(t[N - 1] < (u64{1} << LB), "mul2: result does not fit (V products too large)");
+    h.v[N - 1] = static_cast<u32>(t[N - 1]);
+    return h;
+  }
 
   // a * c for a small constant c, normalised (V grows by the factor c)
   BZ_HD static fe mul_small(const fe& a, u32 c) {
