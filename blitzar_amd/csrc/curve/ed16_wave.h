@@ -20,7 +20,8 @@
 // single wavefront runs: tools/ubench/tail_latency.hip (v_mad_u64_u32 4.0 ns, an LDS write ->
 // read round trip 53 ns).
 //
-// Bounds (checked by interval propagation in the model this was derived from): products leave
+// Bounds (checked by interval propagation in tools/models/ed16_wave_model.py, run by
+// tests/test_ed16_wave_model.py): products leave
 // limbs < 2^16 + 64; the rotated operand must stay < 2^24 / 38 = 2^18.75 and column sums < 2^48.
 // Subtractions add the limb-wise multiple 3p (every limb >= 98301).
 //
