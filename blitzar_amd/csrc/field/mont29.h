@@ -339,19 +339,98 @@ template <class P> struct mont29 {
     to_words(w, canonical(mul(a, c)));
   }
 
-  // a^(p-2); zero for zero.  `a` normalised with V < 8.
+  // 1 / a (zero for zero); `a` normalised with V < 8.
+  // Binary extended Euclid on the canonical integer in 64-bit words: ~2 log2(p) halvings and
+  // subtractions of N64-word numbers, ~9x fewer instructions than the 1.5 log2(p) Montgomery
+  // products of a^(p-2).  It is one dependent chain either way (one inversion per output column,
+  // on one lane), so instructions are what counts: bls12-381 1.2 ms -> 0.15 ms on MI355X.
+  // With A = a R the loop yields A^-1 mod p as a plain integer; one product with R^3 makes it
+  // a^-1 R.
   BZ_HD_NOINLINE static fe invert(const fe& a) {
-    // exponent bits from the limbs of p (p - 2 only changes limb 0, which is >= 2 for all moduli)
-    fe acc = one();
-    for (int i = N - 1; i >= 0; --i) {
-      const u32 e = i == 0 ? P::p(0) - 2 : P::p(i);
-      const int top = i == N - 1 ? 31 - __builtin_clz(P::p(N - 1)) : LB - 1;
-      for (int b = top; b >= 0; --b) {
-        acc = sqr(acc);
-        if ((e >> b) & 1) acc = mul(acc, a);
+    const fe ac = canonical(norm(a));
+    u32 any = 0;
+    for (int i = 0; i < N; ++i) any |= ac.v[i];
+    if (any == 0) return zero();
+    fe pf;
+    for (int i = 0; i < N; ++i) pf.v[i] = P::p(i);
+    u64 p[N64], u[N64], v[N64], x1[N64], x2[N64];
+    to_words(p, pf);
+    to_words(u, ac);
+    for (int k = 0; k < N64; ++k) {
+      v[k] = p[k];
+      x1[k] = k == 0 ? 1 : 0;
+      x2[k] = 0;
+    }
+    auto is_one = [](const u64* w) {
+      u64 rest = 0;
+      for (int k = 1; k < N64; ++k) rest |= w[k];
+      return w[0] == 1 && rest == 0;
+    };
+    auto shr1 = [](u64* w, u64 top_in) {
+      for (int k = 0; k < N64 - 1; ++k) w[k] = (w[k] >> 1) | (w[k + 1] << 63);
+      w[N64 - 1] = (w[N64 - 1] >> 1) | (top_in << 63);
+    };
+    // x / 2 mod p for x < p
+    auto halve = [&](u64* x) {
+      u64 carry = 0;
+      if (x[0] & 1) {
+        for (int k = 0; k < N64; ++k) {
+          const u64 s = x[k] + carry;
+          const u64 c1 = s < carry;
+          x[k] = s + p[k];
+          carry = c1 | (x[k] < s);
+        }
+      }
+      shr1(x, carry);
+    };
+    // w -= z, returns the borrow
+    auto sub = [](u64* w, const u64* z) {
+      u64 borrow = 0;
+      for (int k = 0; k < N64; ++k) {
+        const u64 d = w[k] - z[k];
+        const u64 b1 = w[k] < z[k];
+        w[k] = d - borrow;
+        borrow = b1 | (d < borrow);
+      }
+      return borrow;
+    };
+    auto sub_mod = [&](u64* x, const u64* y) {
+      if (sub(x, y)) {
+        u64 carry = 0;
+        for (int k = 0; k < N64; ++k) {
+          const u64 s = x[k] + carry;
+          const u64 c1 = s < carry;
+          x[k] = s + p[k];
+          carry = c1 | (x[k] < s);
+        }
+      }
+    };
+    auto geq = [](const u64* w, const u64* z) {
+      for (int k = N64 - 1; k >= 0; --k) {
+        if (w[k] != z[k]) return w[k] > z[k];
+      }
+      return true;
+    };
+    while (!is_one(u) && !is_one(v)) {
+      while ((u[0] & 1) == 0) {
+        shr1(u, 0);
+        halve(x1);
+      }
+      while ((v[0] & 1) == 0) {
+        shr1(v, 0);
+        halve(x2);
+      }
+      if (geq(u, v)) {
+        sub(u, v);
+        sub_mod(x1, x2);
+      } else {
+        sub(v, u);
+        sub_mod(x2, x1);
       }
     }
-    return acc;
+    fe r3;
+    for (int i = 0; i < N; ++i) r3.v[i] = P::r3(i);
+    return mul(from_words(is_one(u) ? x1 : x2), r3);
   }
 };
 
