@@ -288,8 +288,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // dynamic LDS so registers stay free -- still queued the side kernels behind the accumulation:
   // 1.74 -> 1.87 ms.)
   ctx.timer.timed(timing, 1, stream, [&] {
-    hipLaunchKernelGGL(k_recode, dim3(ceil_div_u32(plan.max_rows, 256), num_cols), dim3(256), 0,
-                       stream, b.digits, b.cols, b.tasks);
+    const u32 chunks = ceil_div_u32(plan.max_rows, 256);
+    const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
+    const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
+    hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, stream, b.digits, b.cols,
+                       b.tasks, num_cols, chunks);
   });
   BZ_HIP_CHECK(hipMemsetAsync(b.group_cursor, 0, sizeof(u32) * (plan.total_groups + 1), stream));
   ctx.timer.timed(timing, 2, stream, [&] {

@@ -61,18 +61,29 @@ __global__ void __launch_bounds__(256)
 // D_w in [-2^(c-1), 2^(c-1)] with  x = sum_w D_w 2^(c w), and stores E = -D as int16 at
 // digits[task.entry_base + row].  (Storing -D keeps c = 16 inside int16: D in [-32767, 32768].
 // Signed columns use c <= 15, enforced by the planner.)
+// Work item = (column, chunk of 256 rows), numbered so that the workgroups one XCD receives in
+// a row (ids = xcd mod 8) walk through the COLUMNS of one row chunk: the columns of a packed
+// fixed-base call are bit fields of the same rows (`row_stride` ~12 KiB at config 5), so every
+// lane touches its own cache line and the neighbouring columns find it in that XCD's L2.
 static __global__ void __launch_bounds__(256)
     k_recode(i16* __restrict__ digits, const column_desc* __restrict__ columns,
-             const task_desc* __restrict__ tasks) {
-  const column_desc col = columns[blockIdx.y];
-  const u64 row = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (row >= col.n) return;
-  digit_recoder rec;
-  rec.init(col.data + row * col.row_stride, col.bit_offset, col.bit_width, col.is_signed != 0,
-           col.window_bits);
-  for (u32 wi = 0; wi < col.num_windows; ++wi) {
-    const int d = rec.next();
-    digits[tasks[col.first_task + wi].entry_base + row] = static_cast<i16>(-d);
+             const task_desc* __restrict__ tasks, u32 num_columns, u32 num_chunks) {
+  const u64 chunk_groups = (num_chunks + 7) / 8;
+  const u64 total = 8 * chunk_groups * num_columns;
+  for (u64 id = blockIdx.x; id < total; id += gridDim.x) {
+    const u32 xcd = static_cast<u32>(id & 7);
+    const u64 rest = id >> 3;
+    const column_desc col = columns[rest % num_columns];
+    const u64 chunk = (rest / num_columns) * 8 + xcd;
+    const u64 row = chunk * blockDim.x + threadIdx.x;
+    if (row >= col.n) continue;
+    digit_recoder rec;
+    rec.init(col.data + row * col.row_stride, col.bit_offset, col.bit_width, col.is_signed != 0,
+             col.window_bits);
+    for (u32 wi = 0; wi < col.num_windows; ++wi) {
+      const int d = rec.next();
+      digits[tasks[col.first_task + wi].entry_base + row] = static_cast<i16>(-d);
+    }
   }
 }
 
