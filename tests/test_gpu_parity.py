@@ -217,6 +217,39 @@ def test_full_size_properties_curve25519_n2_20(gpu_backend):
     assert np.array_equal(hooks.ristretto_encode(acc), out[4])
 
 
+def test_long_column_properties_n2_23(gpu_backend):
+    """n = 2^23 rows: beyond the sizes the oracle reaches, and a different regime of the two-pass
+    sort (1024 bucket groups of ~8192 records each, all streamed instead of staged in LDS).
+    Size-independent properties: the all-ones column is the prefix sum of the generators,
+    commit(a) + commit(b) == commit(a + b) for 128-bit columns, a column equals the sum of its
+    halves."""
+    from tests import hooks
+    api = gpu_backend
+    n = 1 << 23
+    rng = np.random.default_rng(23)
+    a = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    wa, wb = a.view("<u8"), b.view("<u8")
+    lo = wa[:, 0] + wb[:, 0]
+    carry = (lo < wa[:, 0]).astype(np.uint64)
+    hi = wa[:, 1] + wb[:, 1]
+    carry2 = (hi < wa[:, 1]).astype(np.uint64)
+    hi2 = hi + carry
+    carry2 |= (hi2 < hi).astype(np.uint64)
+    ab = np.zeros((n, 3), dtype=np.uint64)            # 129-bit sums in 24-byte scalars
+    ab[:, 0], ab[:, 1], ab[:, 2] = lo, hi2, carry2
+    ab = ab.view(np.uint8).reshape(n, 24)
+    out = api.compute_pedersen_commitments(0, [(np.ones((n, 1), np.uint8), False), (a, False),
+                                               (b, False), (ab, False)])
+    assert np.array_equal(out[0], hooks.ristretto_encode(api.get_one_commit(n)))
+    pa, pb = hooks.ristretto_decode(out[1]), hooks.ristretto_decode(out[2])
+    assert np.array_equal(hooks.ristretto_encode(hooks.ed_add(pa, pb)), out[3])
+    first = api.compute_pedersen_commitments(0, [(a[:n // 2], False)])
+    second = api.compute_pedersen_commitments(0, [(a[n // 2:], False)], offset_generators=n // 2)
+    both = hooks.ed_add(hooks.ristretto_decode(first[0]), hooks.ristretto_decode(second[0]))
+    assert np.array_equal(hooks.ristretto_encode(both), out[1])
+
+
 def test_row_sharded_fold_on_device(gpu_backend, oracle):
     """the single-GPU half of the row-sharded path: projective partials of two row ranges folded
     and canonicalised == the unsharded commitment"""
