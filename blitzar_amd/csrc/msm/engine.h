@@ -85,6 +85,8 @@ struct msm_context {
 static void configure_sort_kernels() {
   static bool done = false;
   if (done) return;
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recode_packed),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_hist),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true>),
@@ -103,6 +105,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   size_t need = 0;
   need += device_arena::padded(sizeof(column_desc) * num_cols);
   need += device_arena::padded(sizeof(task_desc) * (num_tasks + 1));
+  need += device_arena::padded(sizeof(recode_range) * (num_cols + 1)); // k_recode_packed ranges
   if (needs_addends) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
   need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
   need += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
@@ -126,6 +129,39 @@ template <class C>
 void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const msm_plan& plan, const typename C::addend* d_addends,
                        const void* d_api_generators, hipStream_t stream);
+
+// Column ranges for k_recode_packed, or none when the batch is not a packed fixed-base call:
+// every column must be a field of the same rows (equal strides, base pointers ascending and all
+// inside the first row).
+inline std::vector<recode_range> packed_recode_ranges(const msm_plan& plan) {
+  std::vector<recode_range> ranges;
+  const auto& cols = plan.columns;
+  if (cols.size() < 2) return ranges;
+  const u64 stride = cols[0].row_stride;
+  // bytes of its row a column's recoder reads, from its base pointer (msm/recode.h)
+  auto bytes_of = [](const column_desc& c) { return ((c.bit_offset & 7) + c.bit_width + 7) / 8; };
+  for (size_t i = 0; i < cols.size(); ++i) {
+    if (cols[i].row_stride != stride || cols[i].data == nullptr) return {};
+    if (i > 0 && cols[i].data < cols[i - 1].data) return {};
+    if (static_cast<u64>(cols[i].data - cols[0].data) + bytes_of(cols[i]) > stride) return {};
+  }
+  for (size_t i = 0; i < cols.size();) {
+    recode_range r{cols[i].data, static_cast<u32>(i), 0, 0, 0};
+    size_t j = i;
+    u64 span = 0;
+    while (j < cols.size()) {
+      const u64 end = static_cast<u64>(cols[j].data - r.base) + bytes_of(cols[j]);
+      if (end > kPackedTileSpan) break;
+      if (end > span) span = end;
+      ++j;
+    }
+    r.num_columns = static_cast<u32>(j - i);
+    r.span = static_cast<u32>(span);
+    ranges.push_back(r);
+    i = j;
+  }
+  return ranges;
+}
 
 // Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
 // (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
@@ -231,13 +267,24 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.tasks = ctx.arena.take<task_desc>(num_tasks + 1);
   // descriptors go through pinned staging: `plan` does not outlive this call, the copies do
   const size_t col_bytes = sizeof(column_desc) * num_cols, task_bytes = sizeof(task_desc) * num_tasks;
-  char* staged = static_cast<char*>(ctx.descriptors.acquire(col_bytes + task_bytes));
+  // packed fixed-base call? (columns = bit fields of the same wide rows, in row order): then
+  // k_recode_packed reads the rows through LDS tiles, one range of columns per tile
+  std::vector<recode_range> ranges = packed_recode_ranges(plan);
+  const size_t range_bytes = sizeof(recode_range) * ranges.size();
+  char* staged = static_cast<char*>(ctx.descriptors.acquire(col_bytes + task_bytes + range_bytes));
   std::memcpy(staged, plan.columns.data(), col_bytes);
   if (task_bytes != 0) std::memcpy(staged + col_bytes, plan.tasks.data(), task_bytes);
   BZ_HIP_CHECK(hipMemcpyAsync(b.cols, staged, col_bytes, hipMemcpyHostToDevice, stream));
   if (task_bytes != 0) {
     BZ_HIP_CHECK(hipMemcpyAsync(b.tasks, staged + col_bytes, task_bytes, hipMemcpyHostToDevice,
                                 stream));
+  }
+  recode_range* d_ranges = nullptr;
+  if (range_bytes != 0) {
+    d_ranges = ctx.arena.take<recode_range>(ranges.size());
+    std::memcpy(staged + col_bytes + task_bytes, ranges.data(), range_bytes);
+    BZ_HIP_CHECK(hipMemcpyAsync(d_ranges, staged + col_bytes + task_bytes, range_bytes,
+                                hipMemcpyHostToDevice, stream));
   }
   ctx.descriptors.release(stream);
   if (num_tasks == 0) {
@@ -288,6 +335,13 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // dynamic LDS so registers stay free -- still queued the side kernels behind the accumulation:
   // 1.74 -> 1.87 ms.)
   ctx.timer.timed(timing, 1, stream, [&] {
+    if (d_ranges != nullptr) {
+      hipLaunchKernelGGL(k_recode_packed, dim3(ceil_div_u32(plan.max_rows, kPackedTileRows)),
+                         dim3(kPackedRecodeThreads), kPackedTileBytes, stream, b.digits, b.cols,
+                         b.tasks, d_ranges, static_cast<u32>(ranges.size()),
+                         plan.columns[0].row_stride, plan.max_rows);
+      return;
+    }
     const u32 chunks = ceil_div_u32(plan.max_rows, 256);
     const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
     const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));

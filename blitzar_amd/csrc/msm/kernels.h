@@ -87,6 +87,81 @@ static __global__ void __launch_bounds__(256)
   }
 }
 
+// k_recode for the packed fixed-base calls (cbindings/blitzar_api.h:688-712): the columns are bit
+// fields of the same rows, `row_stride` (~12 KiB at BASELINE configs[4]) apart, so a lane per row
+// touches one cache line per row and column and uses a few bytes of it.  Here a workgroup takes 64
+// rows: for every range of columns whose bytes span at most kPackedTileSpan it copies the rows'
+// span into LDS with aligned 16-byte loads (coalesced along the row), then every wavefront takes
+// columns of the range, lane = row, and recodes from LDS; a task's 64 digits leave as one 128-byte
+// line.
+constexpr u32 kPackedTileRows = 64;
+constexpr u32 kPackedTileSpan = 1984; // bytes of a row one tile covers
+constexpr u32 kPackedTilePitch = kPackedTileSpan + 48; // + alignment slack, 16-byte multiple
+constexpr u32 kPackedRecodeThreads = 1024;
+constexpr u32 kPackedTileBytes = kPackedTileRows * kPackedTilePitch + 64; // + read-ahead of the last field
+struct recode_range {
+  const u8* base; // lowest column base pointer of the range (row 0)
+  u32 first_column, num_columns;
+  u32 span;       // bytes of a row the range needs, from `base`
+  u32 pad;
+};
+
+static __global__ void __launch_bounds__(kPackedRecodeThreads)
+    k_recode_packed(i16* __restrict__ digits, const column_desc* __restrict__ columns,
+                    const task_desc* __restrict__ tasks, const recode_range* __restrict__ ranges,
+                    u32 num_ranges, u64 row_stride, u64 max_rows) {
+  extern __shared__ __attribute__((aligned(16))) u8 tile[];
+  __shared__ u32 row_shift[kPackedTileRows];
+  const u64 row0 = static_cast<u64>(blockIdx.x) * kPackedTileRows;
+  const u32 rows = static_cast<u32>(max_rows - row0 < kPackedTileRows ? max_rows - row0 : kPackedTileRows);
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (u32 ri = 0; ri < num_ranges; ++ri) {
+    const recode_range range = ranges[ri];
+    // rows [row0, row0 + rows) x bytes [base, base + span): 16-byte chunks from the aligned-down
+    // start of every row; row_shift = what the alignment skipped
+    const u32 chunks = (range.span + 15 + 15) / 16;
+    for (u32 idx = tid; idx < rows * chunks; idx += kPackedRecodeThreads) {
+      const u32 r = idx / chunks, k = idx % chunks;
+      const uintptr_t start = reinterpret_cast<uintptr_t>(range.base) + (row0 + r) * row_stride;
+      const uintptr_t aligned = start & ~static_cast<uintptr_t>(15);
+      const uintptr_t lo = aligned + 16 * k; // this chunk covers [lo, lo + 16)
+      u8* dst = tile + r * kPackedTilePitch + 16 * k;
+      if (lo >= start && lo + 16 <= start + range.span) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(lo);
+      } else {
+        // first / last chunk of the row: never touch a byte outside the caller's buffer
+        for (u32 i = 0; i < 16; ++i) {
+          const uintptr_t at = lo + i;
+          dst[i] = at >= start && at < start + range.span ? *reinterpret_cast<const u8*>(at) : 0;
+        }
+      }
+      if (k == 0) row_shift[r] = static_cast<u32>(start & 15);
+    }
+    __syncthreads();
+    for (u32 c = wave; c < range.num_columns; c += kPackedRecodeThreads / 64) {
+      const column_desc col = columns[range.first_column + c];
+      const u64 row = row0 + lane;
+      if (lane < rows && row < col.n) {
+        // ten aligned words from the tile cover the <= 33 bytes of the field
+        const u32 at = lane * kPackedTilePitch + row_shift[lane] +
+                       static_cast<u32>(col.data - range.base);
+        const u32* src = reinterpret_cast<const u32*>(tile + (at & ~3u));
+        u32 words[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) words[i] = src[i];
+        digit_recoder rec;
+        rec.init_words32(words, 8 * (at & 3) + col.bit_offset, col.bit_width, col.is_signed != 0,
+                         col.window_bits);
+        for (u32 wi = 0; wi < col.num_windows; ++wi) {
+          const int d = rec.next();
+          digits[tasks[col.first_task + wi].entry_base + row] = static_cast<i16>(-d);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 //--------------------------------------------------------------------------------------------------
 // sort by bucket: k_group_hist -> k_group_offsets -> k_group_scatter (partition by bucket group)
 // -> k_group_sort (counting sort of one group inside LDS)

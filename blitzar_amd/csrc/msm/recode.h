@@ -51,9 +51,40 @@ struct digit_recoder {
     }
   }
 
+  // the same field given as ten aligned 32-bit words and the bit position (< 40) of the field's
+  // first bit inside them (k_recode_packed reads its LDS tile this way: no byte loads)
+  BZ_HD void load_words32(const u32* __restrict__ d, u32 bit_shift, u32 bit_width) {
+    u64 t[5];
+    for (int i = 0; i < 5; ++i) t[i] = d[2 * i] | (static_cast<u64>(d[2 * i + 1]) << 32);
+    if (bit_shift != 0) {
+      for (int i = 0; i < 4; ++i) t[i] = (t[i] >> bit_shift) | (t[i + 1] << (64 - bit_shift));
+    }
+    for (int i = 0; i < 4; ++i) {
+      const u32 lo = 64 * i;
+      if (bit_width <= lo) {
+        w[i] = 0;
+      } else if (bit_width < lo + 64) {
+        w[i] = t[i] & ((u64{1} << (bit_width - lo)) - 1);
+      } else {
+        w[i] = t[i];
+      }
+    }
+  }
+
   BZ_HD void init(const u8* __restrict__ p, u32 bit_offset, u32 bit_width, bool is_signed,
                   u32 window_bits) {
     load(p, bit_offset, bit_width);
+    start(bit_width, is_signed, window_bits);
+  }
+
+  BZ_HD void init_words32(const u32* __restrict__ d, u32 bit_shift, u32 bit_width, bool is_signed,
+                          u32 window_bits) {
+    load_words32(d, bit_shift, bit_width);
+    start(bit_width, is_signed, window_bits);
+  }
+
+  // w holds the field: set up the digit walk (|x| for negative values of a signed column)
+  BZ_HD void start(u32 bit_width, bool is_signed, u32 window_bits) {
     c = window_bits;
     half = 1u << (c - 1);
     carry = 0;
