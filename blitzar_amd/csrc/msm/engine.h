@@ -130,39 +130,6 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        const msm_plan& plan, const typename C::addend* d_addends,
                        const void* d_api_generators, hipStream_t stream);
 
-// Column ranges for k_recode_packed, or none when the batch is not a packed fixed-base call:
-// every column must be a field of the same rows (equal strides, base pointers ascending and all
-// inside the first row).
-inline std::vector<recode_range> packed_recode_ranges(const msm_plan& plan) {
-  std::vector<recode_range> ranges;
-  const auto& cols = plan.columns;
-  if (cols.size() < 2) return ranges;
-  const u64 stride = cols[0].row_stride;
-  // bytes of its row a column's recoder reads, from its base pointer (msm/recode.h)
-  auto bytes_of = [](const column_desc& c) { return ((c.bit_offset & 7) + c.bit_width + 7) / 8; };
-  for (size_t i = 0; i < cols.size(); ++i) {
-    if (cols[i].row_stride != stride || cols[i].data == nullptr) return {};
-    if (i > 0 && cols[i].data < cols[i - 1].data) return {};
-    if (static_cast<u64>(cols[i].data - cols[0].data) + bytes_of(cols[i]) > stride) return {};
-  }
-  for (size_t i = 0; i < cols.size();) {
-    recode_range r{cols[i].data, static_cast<u32>(i), 0, 0, 0};
-    size_t j = i;
-    u64 span = 0;
-    while (j < cols.size()) {
-      const u64 end = static_cast<u64>(cols[j].data - r.base) + bytes_of(cols[j]);
-      if (end > kPackedTileSpan) break;
-      if (end > span) span = end;
-      ++j;
-    }
-    r.num_columns = static_cast<u32>(j - i);
-    r.span = static_cast<u32>(span);
-    ranges.push_back(r);
-    i = j;
-  }
-  return ranges;
-}
-
 // Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
 // (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
 // Columns are processed in batches bounded by the launch grid (tasks per batch) and by

@@ -94,18 +94,6 @@ static __global__ void __launch_bounds__(256)
 // span into LDS with aligned 16-byte loads (coalesced along the row), then every wavefront takes
 // columns of the range, lane = row, and recodes from LDS; a task's 64 digits leave as one 128-byte
 // line.
-constexpr u32 kPackedTileRows = 64;
-constexpr u32 kPackedTileSpan = 1984; // bytes of a row one tile covers
-constexpr u32 kPackedTilePitch = kPackedTileSpan + 48; // + alignment slack, 16-byte multiple
-constexpr u32 kPackedRecodeThreads = 1024;
-constexpr u32 kPackedTileBytes = kPackedTileRows * kPackedTilePitch + 64; // + read-ahead of the last field
-struct recode_range {
-  const u8* base; // lowest column base pointer of the range (row 0)
-  u32 first_column, num_columns;
-  u32 span;       // bytes of a row the range needs, from `base`
-  u32 pad;
-};
-
 static __global__ void __launch_bounds__(kPackedRecodeThreads)
     k_recode_packed(i16* __restrict__ digits, const column_desc* __restrict__ columns,
                     const task_desc* __restrict__ tasks, const recode_range* __restrict__ ranges,

@@ -233,4 +233,52 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
   }
   return plan;
 }
+
+// k_recode_packed (kernels.h): tile geometry and the column ranges one tile covers
+constexpr u32 kPackedTileRows = 64;
+constexpr u32 kPackedTileSpan = 1984; // bytes of a row one tile covers
+constexpr u32 kPackedTilePitch = kPackedTileSpan + 48; // + alignment slack, 16-byte multiple
+constexpr u32 kPackedRecodeThreads = 1024;
+constexpr u32 kPackedTileBytes = kPackedTileRows * kPackedTilePitch + 64; // + read-ahead of the last field
+struct recode_range {
+  const u8* base; // lowest column base pointer of the range (row 0)
+  u32 first_column, num_columns;
+  u32 span;       // bytes of a row the range needs, from `base`
+  u32 pad;
+};
+
+
+// Column ranges for k_recode_packed, or none when the batch is not a packed fixed-base call:
+// every column must be a field of the same rows (equal strides, base pointers ascending and all
+// inside the first row).
+inline std::vector<recode_range> packed_recode_ranges(const msm_plan& plan) {
+  std::vector<recode_range> ranges;
+  const auto& cols = plan.columns;
+  if (cols.size() < 2) return ranges;
+  const u64 stride = cols[0].row_stride;
+  // bytes of its row a column's recoder reads, from its base pointer (msm/recode.h)
+  auto bytes_of = [](const column_desc& c) { return ((c.bit_offset & 7) + c.bit_width + 7) / 8; };
+  for (size_t i = 0; i < cols.size(); ++i) {
+    if (cols[i].row_stride != stride || cols[i].data == nullptr) return {};
+    if (i > 0 && cols[i].data < cols[i - 1].data) return {};
+    if (static_cast<u64>(cols[i].data - cols[0].data) + bytes_of(cols[i]) > stride) return {};
+  }
+  for (size_t i = 0; i < cols.size();) {
+    recode_range r{cols[i].data, static_cast<u32>(i), 0, 0, 0};
+    size_t j = i;
+    u64 span = 0;
+    while (j < cols.size()) {
+      const u64 end = static_cast<u64>(cols[j].data - r.base) + bytes_of(cols[j]);
+      if (end > kPackedTileSpan) break;
+      if (end > span) span = end;
+      ++j;
+    }
+    r.num_columns = static_cast<u32>(j - i);
+    r.span = static_cast<u32>(span);
+    ranges.push_back(r);
+    i = j;
+  }
+  return ranges;
+}
+
 } // namespace bz

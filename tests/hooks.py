@@ -161,6 +161,16 @@ def plan(ns, bit_widths, signed, max_window_bits=16):
     return per, totals
 
 
+def packed_ranges(offsets, strides, bit_offsets, bit_widths):
+    """column ranges k_recode_packed would use: list of (first_column, num_columns, base, span)"""
+    k = len(offsets)
+    out = np.zeros((k, 4), np.uint32)
+    n = lib().bz_packed_ranges(_p(out), _p(_c(offsets)), _p(_c(strides)),
+                               _p(_c(bit_offsets, np.uint32)), _p(_c(bit_widths, np.uint32)),
+                               ctypes.c_uint32(k))
+    return [tuple(int(v) for v in row) for row in out[:n]]
+
+
 def f29_from_fe51(f):
     out = np.zeros(9, np.uint32)
     lib().bz_f29_from_fe51(_p(out), _p(_c(f)))

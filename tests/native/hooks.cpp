@@ -186,6 +186,32 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
   totals[5] = plan.total_groups;
 }
 
+// column ranges of k_recode_packed (msm/plan.h): columns = bit fields at byte offsets `offset[i]`
+// of rows `stride[i]` bytes apart; out = {first_column, num_columns, base offset, span} per range;
+// returns the number of ranges (0: not a packed batch)
+int bz_packed_ranges(u32* out, const u64* offset, const u64* stride, const u32* bit_offset,
+                     const u32* bit_width, u32 num_columns) {
+  static u8 arena[1];
+  msm_plan plan;
+  for (u32 i = 0; i < num_columns; ++i) {
+    column_desc c{};
+    c.data = offset[i] == ~u64{0} ? nullptr : arena + offset[i];
+    c.n = 100;
+    c.row_stride = stride[i];
+    c.bit_offset = bit_offset[i];
+    c.bit_width = bit_width[i];
+    plan.columns.push_back(c);
+  }
+  const auto ranges = packed_recode_ranges(plan);
+  for (size_t k = 0; k < ranges.size(); ++k) {
+    out[4 * k + 0] = ranges[k].first_column;
+    out[4 * k + 1] = ranges[k].num_columns;
+    out[4 * k + 2] = static_cast<u32>(ranges[k].base - arena);
+    out[4 * k + 3] = ranges[k].span;
+  }
+  return static_cast<int>(ranges.size());
+}
+
 // 9 x 29-bit field of the gfx950 kernels (field/f29.h); limbs in/out are raw u32[9]
 void bz_f29_from_fe51(u32* h, const u64* f) {
   fe51 a;

@@ -181,6 +181,31 @@ def test_planner_invariants():
     assert per[0][0] <= 15
 
 
+def test_packed_recode_ranges():
+    """which batches k_recode_packed takes (packed fixed-base calls: bit fields of the same rows)
+    and how their columns are cut into LDS tiles of at most 1984 row bytes"""
+    # the reference's packed layout: outputs of 8 / 32 / 256 bits back to back (blitzar_api.h:688-712)
+    widths = [[8, 32, 256][i % 3] for i in range(128)]
+    bit_pos = np.concatenate([[0], np.cumsum(widths)[:-1]])
+    stride = (sum(widths) + 7) // 8
+    ranges = hooks.packed_ranges(bit_pos // 8, [stride] * 128, bit_pos % 8, widths)
+    assert ranges == [(0, 128, 0, stride)]                     # 1579 bytes: one tile
+    # a wider row is cut where a column would end beyond 1984 bytes from the range's base
+    widths = [256] * 100
+    bit_pos = np.arange(100) * 256
+    ranges = hooks.packed_ranges(bit_pos // 8, [3200] * 100, bit_pos % 8, widths)
+    assert ranges == [(0, 62, 0, 1984), (62, 38, 1984, 1216)]
+    # unaligned fields: the span counts the straddled bytes
+    ranges = hooks.packed_ranges([0, 0, 1], [4, 4, 4], [0, 3, 1], [3, 6, 23])
+    assert ranges == [(0, 3, 0, 4)]
+    # not packed: separate buffers, different strides, descending bases, a null column
+    assert hooks.packed_ranges([0, 3200], [32, 32], [0, 0], [256, 256]) == []
+    assert hooks.packed_ranges([0, 4], [32, 16], [0, 0], [8, 8]) == []
+    assert hooks.packed_ranges([4, 0], [32, 32], [0, 0], [8, 8]) == []
+    assert hooks.packed_ranges([0, 2**64 - 1], [32, 32], [0, 0], [8, 8]) == []
+    assert hooks.packed_ranges([0], [32], [0], [8]) == []      # single columns use k_recode
+
+
 #--------------------------------------------------------------------------------------------------
 # the 9 x 29-bit field / curve code the gfx950 kernels compute in (field/f29.h, curve/ed29.h)
 #--------------------------------------------------------------------------------------------------
