@@ -37,6 +37,13 @@ WORKLOADS = {
 }
 STAGES = ["prepare_addends", "recode", "bucket_sort", "accumulate", "reduce", "combine"]
 HBM_PEAK_GBS = 8000.0
+# integer-ALU side of k_accumulate (the honest binding bound).  736 v_mad_u64_u32 per
+# bucket addition is the count in the kernel's ISA (8 field products x 92: 81 limb products, 9
+# wrap-arounds, 2 folds); the peak is the measured issue rate of that instruction with every SIMD
+# busy, tools/ubench/valu_rates.hip: one wave-instruction per 5.6 cycles per SIMD at the 2.4 GHz
+# the device reports, x 1024 SIMDs.
+MADS_PER_ADDITION = 736
+PEAK_WAVE_MADS_PER_S = 1024 * 2.4e9 / 5.6
 
 
 def parse_args():
@@ -210,6 +217,16 @@ def main():
                 # the binding bound of this kernel is integer issue, not HBM:
                 # fraction of cycles the SIMDs' VALU was issuing, from the same PMC run
                 "valu_busy": valu_busy,
+            }
+            # one addition per non-zero digit: 252-bit scalars populate ceil(252 / 16) = 16 windows
+            additions = n * ((8 * nbytes - (8 - top_mask.bit_length()) + 15) // 16)
+            wave_mads = additions * MADS_PER_ADDITION / 64
+            result["roofline"]["alu"] = {
+                "instruction": "v_mad_u64_u32",
+                "wave_instructions_per_launch": wave_mads,
+                "achieved_per_s": wave_mads / dur_s,
+                "peak_per_s": PEAK_WAVE_MADS_PER_S,
+                "frac": wave_mads / dur_s / PEAK_WAVE_MADS_PER_S,
             }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_log2n)
