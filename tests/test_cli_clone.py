@@ -43,3 +43,73 @@ def test_multi_commitment_cli(oracle, n, commitments, nbytes):
     want = oracle.commit(0, [(table[c], False) for c in range(commitments)],
                          oracle.ristretto_generators(n))
     assert [bytes(w) for w in want] == got
+
+
+#--------------------------------------------------------------------------------------------------
+# tools/multi_exp: clones of benchmark/multi_exp_pip and benchmark/multi_exp_triangle
+#--------------------------------------------------------------------------------------------------
+EXP_SRC = os.path.join(ROOT, "tools", "multi_exp", "benchmark.cc")
+EXP_EXE = {False: os.path.join(ROOT, "tools", "multi_exp", "_build", "multi_exp_pip"),
+           True: os.path.join(ROOT, "tools", "multi_exp", "_build", "multi_exp_triangle")}
+FIELD_P = {2: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+           3: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}
+
+
+def build_multi_exp(triangle):
+    exe = EXP_EXE[triangle]
+    if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(EXP_SRC):
+        return exe
+    lib_dir = os.path.join(ROOT, "blitzar_amd", "lib")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), EXP_SRC]
+                   + (["-DBZ_TRIANGLE"] if triangle else [])
+                   + ["-L" + lib_dir, "-lblitzar_amd", "-Wl,-rpath," + lib_dir,
+                      "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def reference_generators(oracle, cid, n):
+    """the generators the reference benchmarks use (multi_exp_pip/benchmark.m.cc:84-112), from the
+    reference's own code"""
+    if cid == 0:
+        return oracle.ristretto_generators(n)
+    return np.stack([oracle.random_affine(cid, i + 1, i + 2) for i in range(n)])
+
+
+def run_multi_exp(oracle, curve, cid, n, outputs, nbytes, triangle):
+    exe = build_multi_exp(triangle)
+    env = dict(os.environ, BLITZAR_BACKEND="cpu")
+    out = subprocess.run([exe, curve, str(n), "1", str(outputs), str(nbytes), "1"], env=env,
+                         capture_output=True, text=True, timeout=600, check=True).stdout
+    assert f"running {curve} benchmark..." in out and "compute duration (s): " in out
+    # exponents are drawn output-major, stored row-major (fill_exponents, benchmark.m.cc:117-131)
+    table = mt19937_bytes(outputs * n * nbytes, False).reshape(outputs, n, nbytes)
+    lengths = [n] * outputs
+    if triangle:
+        counter = n - outputs if n > outputs else 0
+        lengths = [min(counter + k + 1, n) for k in range(outputs)]
+    want = oracle.commit(cid, [(table[o][:lengths[o]], False) for o in range(outputs)],
+                         reference_generators(oracle, cid, n))
+    lines = re.findall(r"^(\d+): \{(.*)\}$", out, flags=re.M)
+    assert [int(k) for k, _ in lines] == list(range(outputs))
+    for (_, body), w in zip(lines, want):
+        if cid in (0, 1):
+            assert [int(v) for v in body.rstrip(",").split(",")] == list(w)
+        else:
+            x, y = (int(v.split("_")[0], 16) for v in body.split(", "))
+            p = FIELD_P[cid]
+            r_inv = pow(1 << 256, -1, p)
+            assert x == int.from_bytes(bytes(w[:32]), "little") * r_inv % p
+            assert y == int.from_bytes(bytes(w[32:64]), "little") * r_inv % p
+            assert body.endswith("_f25" if cid == 2 else "_fgk")
+
+
+@pytest.mark.parametrize("curve,cid", [("curve25519", 0), ("bls12_381", 1), ("bn254", 2),
+                                       ("grumpkin", 3)])
+def test_multi_exp_pip_cli(oracle, curve, cid):
+    run_multi_exp(oracle, curve, cid, n=37, outputs=3, nbytes=5, triangle=False)
+
+
+@pytest.mark.parametrize("curve,cid,n,outputs", [("curve25519", 0, 40, 6), ("bn254", 2, 5, 9)])
+def test_multi_exp_triangle_cli(oracle, curve, cid, n, outputs):
+    run_multi_exp(oracle, curve, cid, n=n, outputs=outputs, nbytes=2, triangle=True)
