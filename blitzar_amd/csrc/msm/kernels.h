@@ -9,8 +9,9 @@
 //   k_group_hist       per (task, slice of rows): LDS histogram of the digits by bucket *group*
 //   k_group_offsets    per task: exclusive scan of the group totals -> start of every group
 //   k_group_scatter    per (task, slice): partition the digits into per-group runs of records
-//   k_group_sort       per (task, group; k_group_big_*: chunk of an oversized group): counting sort by bucket inside
-//                      LDS -> `row | sign << 31` list, bucket end offsets, segment -> bucket map
+//   k_group_sort       per (task, group; k_group_big_*: chunk of an oversized group): counting
+//                      sort by bucket inside LDS -> `row | sign << 31` list, bucket end offsets,
+//                      segment -> bucket map
 //                      (together a two-pass radix sort by bucket; reference K1/K2:
 //                       bucket_method2/multiproduct_table_kernel.h:32-93, multiproduct_table.cc:74-82)
 //   k_accumulate       one lane per 32 consecutive *sorted entries* (not per bucket): gather
@@ -36,8 +37,10 @@ namespace bz {
 using i16 = int16_t;
 
 constexpr u32 kSortThreads = 1024;
-constexpr u32 kReduceHeavyHeads = 16; // k_reduce folds buckets with more head partials cooperatively
-constexpr u32 kReduceMaxHeavy = 8;    // ... up to this many per workgroup (the rest stay with their lane)
+// k_reduce folds buckets with more than kReduceHeavyHeads head partials cooperatively, up to
+// kReduceMaxHeavy of them per workgroup (any further ones stay with their lane)
+constexpr u32 kReduceHeavyHeads = 16;
+constexpr u32 kReduceMaxHeavy = 8;
 constexpr u32 kAccumulateThreads = 256;
 constexpr u32 kCombineThreads = 256;
 
@@ -101,7 +104,8 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
   extern __shared__ __attribute__((aligned(16))) u8 tile[];
   __shared__ u32 row_shift[kPackedTileRows];
   const u64 row0 = static_cast<u64>(blockIdx.x) * kPackedTileRows;
-  const u32 rows = static_cast<u32>(max_rows - row0 < kPackedTileRows ? max_rows - row0 : kPackedTileRows);
+  const u32 rows =
+      static_cast<u32>(max_rows - row0 < kPackedTileRows ? max_rows - row0 : kPackedTileRows);
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (u32 ri = 0; ri < num_ranges; ++ri) {
     const recode_range range = ranges[ri];
@@ -180,7 +184,8 @@ static __global__ void __launch_bounds__(kSortThreads)
     k_group_hist(u32* __restrict__ group_total, u32* __restrict__ big_tasks,
                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) big_tasks[0] = 0; // k_group_offsets appends
+  // the list k_group_offsets appends to starts empty
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) big_tasks[0] = 0;
   const task_desc task = tasks[blockIdx.y];
   const u32 slice = blockIdx.x;
   if (slice >= task.num_slices) return;
@@ -606,38 +611,40 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
   __shared__ u32 cursor[1u << kMaxGroupBits];
   const u32 num_big_tasks = big_tasks[0];
   for (u32 t = 0; t < num_big_tasks; ++t) {
-  const task_desc task = tasks[big_tasks[1 + t]];
-  const u32* gc = group_chunk + task.group_base;
-  const u32 big_chunks = gc[task.num_groups];
-  const u32 s = task.group_bits, buckets = 1u << s;
-  const u32 tid = threadIdx.x;
-  const u32 in_group = buckets - 1, shift = 31 - s;
-  const u32* gs = group_start + task.group_base;
-  // every workgroup of the launch takes chunks of every listed task, starting at a different one
-  for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
-    const u32 g = locate_big_group(gc, task.num_groups, index);
-    const u32 begin = gs[g] + (index - gc[g]) * kLocalSortCapacity;
-    const u32 total = gs[g + 1] - begin < kLocalSortCapacity ? gs[g + 1] - begin : kLocalSortCapacity;
-    for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
-    lds_barrier();
-    const u32* rec = records + task.entry_base + begin;
-    u32 mine[kLocalSortPerThread];
+    const task_desc task = tasks[big_tasks[1 + t]];
+    const u32* gc = group_chunk + task.group_base;
+    const u32 big_chunks = gc[task.num_groups];
+    const u32 s = task.group_bits, buckets = 1u << s;
+    const u32 tid = threadIdx.x;
+    const u32 in_group = buckets - 1, shift = 31 - s;
+    const u32* gs = group_start + task.group_base;
+    // every workgroup of the launch takes chunks of every listed task, starting at a different one
+    for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
+      const u32 g = locate_big_group(gc, task.num_groups, index);
+      const u32 begin = gs[g] + (index - gc[g]) * kLocalSortCapacity;
+      const u32 left = gs[g + 1] - begin;
+      const u32 total = left < kLocalSortCapacity ? left : kLocalSortCapacity;
+      for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
+      lds_barrier();
+      const u32* rec = records + task.entry_base + begin;
+      u32 mine[kLocalSortPerThread];
 #pragma unroll
-    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      const u32 i = tid + k * kGroupSortThreads;
-      mine[k] = i < total ? rec[i] : 0;
-    }
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        const u32 i = tid + k * kGroupSortThreads;
+        mine[k] = i < total ? rec[i] : 0;
+      }
 #pragma unroll
-    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      wave_aggregated_add(cursor, (mine[k] >> shift) & in_group, tid + k * kGroupSortThreads < total);
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        wave_aggregated_add(cursor, (mine[k] >> shift) & in_group,
+                            tid + k * kGroupSortThreads < total);
+      }
+      lds_barrier();
+      u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
+      for (u32 b = tid; b < buckets; b += kGroupSortThreads) {
+        if (cursor[b] != 0) atomicAdd(&counts[b], cursor[b]);
+      }
+      lds_barrier(); // cursor is reused by the next chunk
     }
-    lds_barrier();
-    u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
-    for (u32 b = tid; b < buckets; b += kGroupSortThreads) {
-      if (cursor[b] != 0) atomicAdd(&counts[b], cursor[b]);
-    }
-    lds_barrier(); // cursor is reused by the next chunk
-  }
   }
 }
 
@@ -656,99 +663,101 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
   __shared__ u32 wave_sums[kGroupSortThreads / 64];
   const u32 num_big_tasks = big_tasks[0];
   for (u32 t = 0; t < num_big_tasks; ++t) {
-  const task_desc task = tasks[big_tasks[1 + t]];
-  const u32* gc = group_chunk + task.group_base;
-  const u32 big_chunks = gc[task.num_groups];
-  const u32 s = task.group_bits, buckets = 1u << s;
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32* gs = group_start + task.group_base;
-  const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
-  // block-wide exclusive scan of two adjacent values per lane (b0 = 2 tid)
-  const u32 b0 = 2 * tid;
-  auto scan_pairs = [&](u32 v0, u32 v1, u32& start0, u32& start1) {
-    const u32 local = v0 + v1;
-    u32 incl = local;
+    const task_desc task = tasks[big_tasks[1 + t]];
+    const u32* gc = group_chunk + task.group_base;
+    const u32 big_chunks = gc[task.num_groups];
+    const u32 s = task.group_bits, buckets = 1u << s;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32* gs = group_start + task.group_base;
+    const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
+    // block-wide exclusive scan of two adjacent values per lane (b0 = 2 tid)
+    const u32 b0 = 2 * tid;
+    auto scan_pairs = [&](u32 v0, u32 v1, u32& start0, u32& start1) {
+      const u32 local = v0 + v1;
+      u32 incl = local;
 #pragma unroll
-    for (u32 off = 1; off < 64; off <<= 1) {
-      const u32 up = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += up;
-    }
-    lds_barrier(); // wave_sums of an earlier scan have been read
-    if (lane == 63) wave_sums[wave] = incl;
-    lds_barrier();
-    start0 = incl - local;
-    for (u32 w = 0; w < wave; ++w) start0 += wave_sums[w];
-    start1 = start0 + v0;
-  };
-  for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
-    const u32 g = locate_big_group(gc, task.num_groups, index);
-    const u32 chunk = index - gc[g];
-    const u32 group_begin = gs[g], group_end = gs[g + 1];
-    const u32 begin = group_begin + chunk * kLocalSortCapacity;
-    const u32 total = group_end - begin < kLocalSortCapacity ? group_end - begin : kLocalSortCapacity;
-    const u32* rec = records + task.entry_base + begin;
-    u32 mine[kLocalSortPerThread];
-#pragma unroll
-    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      const u32 i = tid + k * kGroupSortThreads;
-      mine[k] = i < total ? rec[i] : 0;
-    }
-    // the group's bucket starts from the global histogram
-    const u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
-    const u32 g0 = b0 < buckets ? counts[b0] : 0, g1 = b0 + 1 < buckets ? counts[b0 + 1] : 0;
-    u32 gstart0, gstart1;
-    scan_pairs(g0, g1, gstart0, gstart1);
-    if (chunk == 0) {
-      u32* ends = bucket_end + task.bucket_base + (static_cast<u64>(g) << s);
-      if (b0 < buckets) ends[b0] = group_begin + gstart0 + g0;
-      if (b0 + 1 < buckets) ends[b0 + 1] = group_begin + gstart1 + g1;
-    }
-    // the chunk's own histogram
-    for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
-    lds_barrier();
-#pragma unroll
-    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      wave_aggregated_add(cursor, (mine[k] >> shift) & in_group, tid + k * kGroupSortThreads < total);
-    }
-    lds_barrier();
-    const u32 c0 = b0 < buckets ? cursor[b0] : 0, c1 = b0 + 1 < buckets ? cursor[b0 + 1] : 0;
-    u32 lstart0, lstart1;
-    scan_pairs(c0, c1, lstart0, lstart1);
-    u32* fill = bucket_fill + task.bucket_base + (static_cast<u64>(g) << s);
-    if (b0 < buckets) {
-      local_start[b0] = lstart0;
-      cursor[b0] = lstart0;
-      run_base[b0] = gstart0 + (c0 != 0 ? atomicAdd(&fill[b0], c0) : 0);
-    }
-    if (b0 + 1 < buckets) {
-      local_start[b0 + 1] = lstart1;
-      cursor[b0 + 1] = lstart1;
-      run_base[b0 + 1] = gstart1 + (c1 != 0 ? atomicAdd(&fill[b0 + 1], c1) : 0);
-    }
-    lds_barrier();
-#pragma unroll
-    for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      const bool active = tid + k * kGroupSortThreads < total;
-      const u32 b = (mine[k] >> shift) & in_group;
-      const u32 pos = wave_aggregated_add(cursor, b, active);
-      if (active) {
-        staging[pos] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
-        staged_bucket[pos] = static_cast<unsigned short>(b);
+      for (u32 off = 1; off < 64; off <<= 1) {
+        const u32 up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
       }
-    }
-    lds_barrier();
-    u32* out = sorted + task.entry_base + group_begin;
-    u32* seg = segment_bucket + task.segment_base;
-    for (u32 i = tid; i < total; i += kGroupSortThreads) {
-      const u32 b = staged_bucket[i];
-      const u32 at = run_base[b] + (i - local_start[b]); // group-relative position
-      out[at] = staging[i];
-      if ((group_begin + at) % kSegmentEntries == 0) {
-        seg[(group_begin + at) / kSegmentEntries] = (g << s) + b;
+      lds_barrier(); // wave_sums of an earlier scan have been read
+      if (lane == 63) wave_sums[wave] = incl;
+      lds_barrier();
+      start0 = incl - local;
+      for (u32 w = 0; w < wave; ++w) start0 += wave_sums[w];
+      start1 = start0 + v0;
+    };
+    for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
+      const u32 g = locate_big_group(gc, task.num_groups, index);
+      const u32 chunk = index - gc[g];
+      const u32 group_begin = gs[g], group_end = gs[g + 1];
+      const u32 begin = group_begin + chunk * kLocalSortCapacity;
+      const u32 left = group_end - begin;
+      const u32 total = left < kLocalSortCapacity ? left : kLocalSortCapacity;
+      const u32* rec = records + task.entry_base + begin;
+      u32 mine[kLocalSortPerThread];
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        const u32 i = tid + k * kGroupSortThreads;
+        mine[k] = i < total ? rec[i] : 0;
       }
+      // the group's bucket starts from the global histogram
+      const u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
+      const u32 g0 = b0 < buckets ? counts[b0] : 0, g1 = b0 + 1 < buckets ? counts[b0 + 1] : 0;
+      u32 gstart0, gstart1;
+      scan_pairs(g0, g1, gstart0, gstart1);
+      if (chunk == 0) {
+        u32* ends = bucket_end + task.bucket_base + (static_cast<u64>(g) << s);
+        if (b0 < buckets) ends[b0] = group_begin + gstart0 + g0;
+        if (b0 + 1 < buckets) ends[b0 + 1] = group_begin + gstart1 + g1;
+      }
+      // the chunk's own histogram
+      for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
+      lds_barrier();
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        wave_aggregated_add(cursor, (mine[k] >> shift) & in_group,
+                            tid + k * kGroupSortThreads < total);
+      }
+      lds_barrier();
+      const u32 c0 = b0 < buckets ? cursor[b0] : 0, c1 = b0 + 1 < buckets ? cursor[b0 + 1] : 0;
+      u32 lstart0, lstart1;
+      scan_pairs(c0, c1, lstart0, lstart1);
+      u32* fill = bucket_fill + task.bucket_base + (static_cast<u64>(g) << s);
+      if (b0 < buckets) {
+        local_start[b0] = lstart0;
+        cursor[b0] = lstart0;
+        run_base[b0] = gstart0 + (c0 != 0 ? atomicAdd(&fill[b0], c0) : 0);
+      }
+      if (b0 + 1 < buckets) {
+        local_start[b0 + 1] = lstart1;
+        cursor[b0 + 1] = lstart1;
+        run_base[b0 + 1] = gstart1 + (c1 != 0 ? atomicAdd(&fill[b0 + 1], c1) : 0);
+      }
+      lds_barrier();
+#pragma unroll
+      for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+        const bool active = tid + k * kGroupSortThreads < total;
+        const u32 b = (mine[k] >> shift) & in_group;
+        const u32 pos = wave_aggregated_add(cursor, b, active);
+        if (active) {
+          staging[pos] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
+          staged_bucket[pos] = static_cast<unsigned short>(b);
+        }
+      }
+      lds_barrier();
+      u32* out = sorted + task.entry_base + group_begin;
+      u32* seg = segment_bucket + task.segment_base;
+      for (u32 i = tid; i < total; i += kGroupSortThreads) {
+        const u32 b = staged_bucket[i];
+        const u32 at = run_base[b] + (i - local_start[b]); // group-relative position
+        out[at] = staging[i];
+        if ((group_begin + at) % kSegmentEntries == 0) {
+          seg[(group_begin + at) / kSegmentEntries] = (g << s) + b;
+        }
+      }
+      lds_barrier(); // the LDS arrays are reused by the next chunk
     }
-    lds_barrier(); // the LDS arrays are reused by the next chunk
-  }
   }
 }
 

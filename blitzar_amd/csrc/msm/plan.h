@@ -239,7 +239,8 @@ constexpr u32 kPackedTileRows = 64;
 constexpr u32 kPackedTileSpan = 1984; // bytes of a row one tile covers
 constexpr u32 kPackedTilePitch = kPackedTileSpan + 48; // + alignment slack, 16-byte multiple
 constexpr u32 kPackedRecodeThreads = 1024;
-constexpr u32 kPackedTileBytes = kPackedTileRows * kPackedTilePitch + 64; // + read-ahead of the last field
+// + the read-ahead of the last field
+constexpr u32 kPackedTileBytes = kPackedTileRows * kPackedTilePitch + 64;
 struct recode_range {
   const u8* base; // lowest column base pointer of the range (row 0)
   u32 first_column, num_columns;
