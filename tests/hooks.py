@@ -152,6 +152,16 @@ def recode(row_bytes, bit_offset, bit_width, is_signed, window_bits, num_windows
     return digits
 
 
+def recode_words32(row_bytes, skew, bit_offset, bit_width, is_signed, window_bits, num_windows):
+    row = np.zeros(len(row_bytes) + 48, np.uint8)
+    row[:len(row_bytes)] = row_bytes
+    digits = np.zeros(num_windows, np.int32)
+    lib().bz_recode_words32(_p(digits), _p(row), ctypes.c_uint32(skew), ctypes.c_uint32(bit_offset),
+                            ctypes.c_uint32(bit_width), ctypes.c_int(1 if is_signed else 0),
+                            ctypes.c_uint32(window_bits), ctypes.c_uint32(num_windows))
+    return digits
+
+
 def plan(ns, bit_widths, signed, max_window_bits=16):
     k = len(ns)
     per = np.zeros((k, 6), np.uint32)

@@ -155,6 +155,19 @@ int bz_recode(int* digits, const u8* row, u32 bit_offset, u32 bit_width, int is_
   return static_cast<int>(num_windows);
 }
 
+// digit_recoder::load_words32 (the LDS-tile path of k_recode_packed) against ::load: the field of
+// `bit_width` bits at `bit_offset` of the row, read from ten aligned words at byte `skew` (0..3)
+int bz_recode_words32(int* digits, const u8* row, u32 skew, u32 bit_offset, u32 bit_width,
+                      int is_signed, u32 window_bits, u32 num_windows) {
+  u32 words[12] = {};
+  // the field starts at byte (bit_offset >> 3) of `row`; place that byte at `skew` in the words
+  std::memcpy(reinterpret_cast<u8*>(words) + skew, row + (bit_offset >> 3), 34);
+  digit_recoder rec;
+  rec.init_words32(words, 8 * skew + (bit_offset & 7), bit_width, is_signed != 0, window_bits);
+  for (u32 w = 0; w < num_windows; ++w) digits[w] = rec.next();
+  return static_cast<int>(num_windows);
+}
+
 // planner (msm/plan.h): per column {window_bits, num_windows, slices, first_task, slice_rows,
 // group_bits}; totals {tasks, total_buckets, total_entries, total_segments, rows covered,
 // total_groups}
@@ -306,6 +319,14 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
   }                                                                                                \
   void bz_##PFX##_29_field_invert(u64* h, const u64* f) {                                          \
     G::F::to_mont64(h, G::F::invert(G::F::from_mont64(f)));                                        \
+  }                                                                                                \
+  /* (2a) b + c (3d) by one fused reduction (mul2): lazily added operands, B 2 x 1 + 1 x 3 */       \
+  void bz_##PFX##_29_field_mul2(u64* h, const u64* a, const u64* b, const u64* c, const u64* d) {  \
+    using F = G::F;                                                                                \
+    const auto fa = F::from_mont64(a), fb = F::from_mont64(b), fc = F::from_mont64(c),             \
+               fd = F::from_mont64(d);                                                             \
+    const auto lhs = F::mul2(F::add(fa, fa), fb, fc, F::add(F::add(fd, fd), fd));                  \
+    F::to_mont64(h, lhs);                                                                          \
   }                                                                                                \
   void bz_##PFX##_29_add(u64* out, const u64* a, const u64* b) {                                   \
     G::G64::point p, q;                                                                            \

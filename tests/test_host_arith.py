@@ -181,6 +181,22 @@ def test_planner_invariants():
     assert per[0][0] <= 15
 
 
+def test_recode_from_aligned_words():
+    """digit_recoder::load_words32 (what k_recode_packed reads from its LDS tile) == ::load"""
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        width = int(rng.integers(1, 257))
+        offset = int(rng.integers(0, 64))
+        signed = bool(rng.integers(0, 2)) and width <= 128
+        c = int(rng.integers(2, 16 if signed else 17))
+        windows = (width + 1 + c - 1) // c
+        row = rng.integers(0, 256, 48, dtype=np.uint8)
+        want = hooks.recode(row, offset, width, signed, c, windows)
+        for skew in range(4):
+            assert np.array_equal(hooks.recode_words32(row, skew, offset, width, signed, c, windows),
+                                  want)
+
+
 def test_packed_recode_ranges():
     """which batches k_recode_packed takes (packed fixed-base calls: bit fields of the same rows)
     and how their columns are cut into LDS tiles of at most 1984 row bytes"""
@@ -322,6 +338,17 @@ def test_mont29_field_matches_reference(oracle, cid):
     for f in elems[:6]:
         inv = hooks.sw29_field(cid, "invert", f)
         assert np.array_equal(hooks.sw29_field(cid, "mul", f, inv), one)
+    # mul2: (2a) b + c (3d) with ONE Montgomery reduction == 2 ab + 3 cd
+    p = {1: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+         2: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+         3: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}[cid]
+    to_int = lambda w: int.from_bytes(w.tobytes(), "little")  # noqa: E731
+    r_inv = pow(1 << (64 * nl), -1, p)
+    for _ in range(60):
+        a, b, c, d = (elems[int(rng.integers(len(elems)))] for _ in range(4))
+        got = to_int(hooks.sw29_field(cid, "mul2", a, b, c, d))
+        want = (2 * to_int(a) * to_int(b) + 3 * to_int(c) * to_int(d)) * r_inv % p
+        assert got == want
 
 
 @pytest.mark.parametrize("cid", [1, 2, 3])
