@@ -6,16 +6,21 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic input: on every rank one
-commitment column of 2^20 uniformly random 252-bit scalars against 2^20 resident ristretto
-generators (BASELINE.json configs[1]; generators = the built-in compute_base_element(i), the
-recipe of benchmark/multi_commitment/benchmark.m.cc:141-156).  Inputs are resident in HBM before
-the timed region.  With N ranks the job is N independent columns (columns shard),
-followed by one RCCL all-gather of the N 32-byte commitments -- weak scaling.
+commitment column of 2^20 uniform 252-bit scalars -- the `std::mt19937{rank}` byte stream of the
+reference benchmark (benchmark/multi_commitment/benchmark.m.cc:141-156), top nibble masked --
+against 2^20 caller-supplied ristretto generators compute_base_element(i) (BASELINE.json
+configs[1]).  Inputs are resident in HBM before the timed region.  With N ranks the job is N
+independent columns (columns shard) followed by one RCCL all-gather of the N 32-byte
+commitments -- weak scaling.
 
-Prints ONE JSON line (rank 0): metric = scalar-point ops / s over the whole job.
-Extra legs, rank 0 / N = 1 only: `roofline` (dominant kernel k_accumulate: algorithmic bytes per
-launch / its HIP-event duration vs 8 TB/s) and `cpu_baseline` (the reference's own CPU backend,
-oracle/_ref, timed on a bounded sample of the same workload on this box's host cores).
+Prints ONE JSON line (rank 0): metric = scalar-point ops / s over the whole job.  Extra members:
+  roofline      dominant kernel k_accumulate: algorithmic bytes per launch / its HIP-event duration
+                against 8 TB/s, plus the integer-ALU side (the binding bound)
+  cpu_baseline  N = 1 only: the reference's own CPU backend (oracle/_ref) on THE SAME scalars; the
+                timed GPU commitment must equal its output or the bench aborts (`verified`)
+  configs       N = 1: BASELINE configs 1, 3, 4, 5 at their stated shapes on one GPU, each with
+                ms_per_call, its roofline, a bounded cpu_baseline sample and a full-size parity
+                check of every output; N > 1: config 4's 256 columns sharded over the ranks
 """
 import argparse
 import ctypes
@@ -29,59 +34,320 @@ import torch  # first: libblitzar_amd.so must bind to the HIP runtime torch alre
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from blitzar_amd import api  # noqa: E402
+import baseline_workloads as wl  # noqa: E402
 
-WORKLOADS = {
-    # name: (curve_id, log2 rows, scalar bytes, top-byte mask, generator bytes per row (C ABI))
-    "curve25519_msm_n2^20_252bit": (api.SXT_CURVE_RISTRETTO255, 20, 32, 0x0f, 160),
-}
 STAGES = ["prepare_addends", "recode", "bucket_sort", "accumulate", "reduce", "combine"]
 HBM_PEAK_GBS = 8000.0
-# integer-ALU side of k_accumulate (the honest binding bound).  736 v_mad_u64_u32 per
-# bucket addition is the count in the kernel's ISA (8 field products x 92: 81 limb products, 9
-# wrap-arounds, 2 folds); the peak is the measured issue rate of that instruction with every SIMD
-# busy, tools/ubench/valu_rates.hip: one wave-instruction per 5.6 cycles per SIMD at the 2.4 GHz
-# the device reports, x 1024 SIMDs.
-MADS_PER_ADDITION = 736
-PEAK_WAVE_MADS_PER_S = 1024 * 2.4e9 / 5.6
+# integer-ALU side of k_accumulate (the honest binding bound).  v_mad_u64_u32 per
+# bucket addition = the count in the kernel's ISA (field products x 92: 81 limb products, 9
+# wrap-arounds, 2 folds).  Peak: the instruction issues once per 4 shader cycles per SIMD
+# (profiles/round2_valu_rates.md: twice the 2 cycles of a plain VALU op), 1024 SIMDs; the clock is
+# the effective shader clock the same micro-benchmark measures under an all-SIMD integer load.
+MADS_PER_ADDITION = {"cached": 736, "niels": 644}
+SIMDS = 1024
+MAD_ISSUE_CYCLES = 4.0
+EFFECTIVE_CLOCK_HZ = 2.1e9  # refined from profiles/alu_calibration.json when present
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=None, help="override rows (debug only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=20,
-                    help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the reference-CPU leg (and with it the output verification)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/4/5 legs")
+    ap.add_argument("--config-steps", type=int, default=3)
     return ap.parse_args()
 
 
-def cpu_baseline(log2n):
-    """reference CPU backend (oracle/_ref) on a bounded sample of the same workload"""
-    from oracle import ref_oracle
-    if not ref_oracle.available():
-        return None
-    n = 1 << log2n
-    rng = np.random.default_rng(0)
-    scalars = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-    scalars[:, 31] &= 0x0f
-    gens = ref_oracle.ristretto_generators(n)
+def vp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def load_oracle():
+    from oracle import ref_oracle  # the checker / CPU baseline; never the thing measured
+    return ref_oracle if ref_oracle.available() else None
+
+
+def alu_calibration():
+    path = os.path.join(ROOT, "profiles", "alu_calibration.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh)
+    return {}
+
+
+class StageClock:
+    """HIP-event stage timing of the engine (bzamd_stage_timing_*), per call"""
+
+    def __init__(self, lib, calls):
+        self.lib = lib
+        lib.bzamd_stage_timing_begin(calls)
+
+    def collect(self, calls_expected):
+        ms = (ctypes.c_double * 6)()
+        batches = self.lib.bzamd_stage_timing_collect(ms)
+        per_call = {STAGES[i]: ms[i] / max(calls_expected, 1) for i in range(6)}
+        return per_call, batches
+
+
+def timed_calls(lib, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    clock = StageClock(lib, steps * 64)
     t0 = time.perf_counter()
-    ref_oracle.commit(0, [(scalars, False)], gens)
-    dt = time.perf_counter() - t0
-    return {
-        "value": n / dt,
-        "unit": "scalar-point ops/s",
-        "cores": 1,
-        "kind": "reference",
-        "sample": f"1 column x 2^{log2n} rows of the same workload (252-bit scalars, built-in "
-                  f"generators), {dt:.2f} s on 1 of {os.cpu_count()} host cores; the reference cpu "
-                  "backend is single-threaded and its ops/s falls with n",
-    }
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stages, _ = clock.collect(steps)
+    return dt, stages
 
 
+def roofline_of(kernel, alg_bytes, accumulate_ms):
+    achieved = alg_bytes / (accumulate_ms * 1e-3) / 1e9 if accumulate_ms > 0 else 0.0
+    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_call": alg_bytes, "kernel_ms_per_call": accumulate_ms}
+
+
+#--------------------------------------------------------------------------------------------------
+# configs 1, 3, 4, 5 (N = 1)
+#--------------------------------------------------------------------------------------------------
+def config1(oracle):
+    """curve25519, 1 column x 2^16 rows, SXT_CPU_BACKEND (plumbing, no GPU): a subprocess, the
+    backend is chosen once per process"""
+    import subprocess
+    code = (
+        "import sys, time, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tools')!r})\n"
+        "from blitzar_amd import api\n"
+        "import baseline_workloads as wl\n"
+        "assert api.init(api.SXT_CPU_BACKEND, 1 << 16) == 0\n"
+        "s = wl.mt19937_scalars(1, 1 << 16, 32)[0]\n"
+        "api.compute_pedersen_commitments(0, [(s[:256], False)])\n"
+        "t0 = time.perf_counter(); out = api.compute_pedersen_commitments(0, [(s, False)])\n"
+        "print(json.dumps({'s': time.perf_counter() - t0, 'out': out[0].tolist()}))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       check=True)
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    n = 1 << 16
+    entry = {"config": "1: curve25519 Pedersen commitment, 1 column x 2^16 rows, cpu backend",
+             "backend": "SXT_CPU_BACKEND (host code of this library, 1 thread)",
+             "ms_per_call": got["s"] * 1e3, "scalar_point_ops_per_s": n / got["s"],
+             "data": "mt19937{0} bytes, 32-byte scalars, built-in generators",
+             "roofline": None}
+    if oracle is not None:
+        s = wl.mt19937_scalars(1, n, 32)[0]
+        gens = oracle.ristretto_generators(n)
+        t0 = time.perf_counter()
+        want = oracle.commit(0, [(s, False)], gens)
+        dt = time.perf_counter() - t0
+        assert want[0].tolist() == got["out"], "config 1: host backend disagrees with the reference"
+        entry["verified"] = "bit-exact vs the reference CPU backend on the same scalars"
+        entry["cpu_baseline"] = {"value": n / dt, "unit": "scalar-point ops/s", "cores": 1,
+                                 "kind": "reference",
+                                 "sample": f"the full config: 1 column x 2^16 rows, {dt:.2f} s"}
+    return entry
+
+
+def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps, dev, stream,
+                         cpu_sample_log2n):
+    n = 1 << log2n
+    assert oracle is not None, "configs 3-5 build their generator sets from the reference's base point"
+    base, gens = wl.dlog_generators(lib, oracle, cid, n, dev, stream)
+    out = torch.zeros((columns, api.CURVE_LAYOUT[cid][1]), dtype=torch.uint8, device=dev)
+    desc = (api.sxt_sequence_descriptor * columns)()
+    for c in range(columns):
+        desc[c] = api.sxt_sequence_descriptor(32, n, scalars[c].data_ptr(), 0)
+
+    def step():
+        lib.bzamd_msm_device(cid, vp(out), columns, desc, vp(gens), stream)
+
+    dt, stages = timed_calls(lib, step, steps, 1)
+    got = out.cpu().numpy()
+    bad = []
+    for c in range(columns):
+        sums = wl.weighted_byte_sums(scalars[c])
+        want = wl.expected_canonical(oracle, cid, base, wl.weighted_scalar_sum(sums, 0, 32))
+        if not np.array_equal(got[c], want[:got.shape[1]]):
+            bad.append(c)
+    assert not bad, f"{name}: columns {bad} differ from the reference"
+    ops = columns * n
+    stride = api.CURVE_LAYOUT[cid][0]
+    alg_bytes = ops * 32 + n * stride + columns * api.CURVE_LAYOUT[cid][1]
+    entry = {"config": name, "rows": n, "columns": columns, "ms_per_call": dt * 1e3,
+             "scalar_point_ops_per_s": ops / dt, "commitments_per_s": columns / dt,
+             "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
+             "verified": f"all {columns} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
+                         "encoded by the reference's curve code",
+             "roofline": roofline_of(f"k_accumulate<curve {cid}>", alg_bytes, stages["accumulate"])}
+    # CPU sample: the reference backend on one column of 2^cpu_sample_log2n rows of this workload
+    m = 1 << cpu_sample_log2n
+    g_host = gens[:m].cpu().numpy()
+    s_host = scalars[0][:m].cpu().numpy()
+    t0 = time.perf_counter()
+    want = oracle.commit(cid, [(s_host, False)], g_host)
+    cdt = time.perf_counter() - t0
+    sums = wl.weighted_byte_sums(scalars[0][:m])
+    chk = wl.expected_canonical(oracle, cid, base, wl.weighted_scalar_sum(sums, 0, 32))
+    assert np.array_equal(want[0], chk[:want.shape[1]])
+    entry["cpu_baseline"] = {
+        "value": m / cdt, "unit": "scalar-point ops/s", "cores": 1, "kind": "reference",
+        "sample": f"1 column x 2^{cpu_sample_log2n} rows of this workload, {cdt:.2f} s on 1 core; "
+                  "columns are independent and the reference's ops/s falls with n, so the full "
+                  "config is at best this rate"}
+    return entry
+
+
+def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
+    cid, n = 3, 1 << log2n
+    base, gens = wl.dlog_generators(lib, oracle, cid, n, dev, stream)
+    gens_host = gens.cpu().numpy()
+    t0 = time.perf_counter()
+    handle = api.MultiexpHandle(cid, oracle.affine_to_projective(cid, gens_host))
+    handle_s = time.perf_counter() - t0
+    bit_table = wl.config5_bit_table(outputs)
+    row_bytes = (int(bit_table.sum()) + 7) // 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    scalars = torch.randint(0, 256, (n, row_bytes), dtype=torch.uint8, device=dev, generator=g)
+    offs = (np.concatenate([[0], np.cumsum(bit_table)[:-1]]) // 8).astype(np.int64)
+    wide = torch.from_numpy(offs[bit_table == 256] + 31).to(dev)
+    scalars[:, wide] &= 0x0f
+    psize = api.CURVE_LAYOUT[cid][2]
+    res = torch.zeros((outputs, psize), dtype=torch.uint8, device=dev)
+
+    def step():
+        lib.bzamd_fixed_packed_multiexponentiation_device(
+            vp(res), handle._h, bit_table.ctypes.data_as(ctypes.c_void_p), None, outputs, n,
+            vp(scalars), stream)
+
+    dt, stages = timed_calls(lib, step, steps, 1)
+    got = res.cpu().numpy()
+    sums = wl.weighted_byte_sums(scalars)
+    bad = []
+    for k in range(outputs):
+        want = wl.expected_canonical(oracle, cid, base, wl.weighted_scalar_sum(
+            sums, int(offs[k]), int(bit_table[k]) // 8))
+        have = np.ascontiguousarray(oracle.canonical(cid, got[k].view(np.uint64))).view(np.uint8)
+        if not np.array_equal(have.reshape(-1), want):
+            bad.append(k)
+    assert not bad, f"config 5: outputs {bad} differ from the reference"
+    handle.close()
+    ops = outputs * n
+    alg_bytes = n * row_bytes + outputs * psize
+    entry = {"config": f"5: grumpkin packed fixed-base, {outputs} outputs x 2^{log2n} rows, "
+                       "8/32/256-bit fields", "rows": n, "outputs": outputs,
+             "bits_per_row": int(bit_table.sum()), "ms_per_call": dt * 1e3,
+             "row_output_ops_per_s": ops / dt, "outputs_per_s": outputs / dt,
+             "handle_creation_s": handle_s,
+             "data": "torch device generator (3.3e9 draws of a serial mt19937 take 83 s)",
+             "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
+             "verified": f"all {outputs} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
+                         "encoded by the reference's curve code",
+             "roofline": roofline_of("k_accumulate<grumpkin>", alg_bytes, stages["accumulate"])}
+    # CPU sample: the reference's fixed-base path does not compile here (CUDA-only headers); its
+    # variable-base CPU backend on one 8-, one 32- and one 256-bit output of 2^14 rows
+    m = 1 << 14
+    cols = []
+    for k in range(3):
+        nb = int(bit_table[k]) // 8
+        cols.append((scalars[:m, int(offs[k]):int(offs[k]) + nb].cpu().numpy().copy(), False))
+    t0 = time.perf_counter()
+    oracle.commit(cid, cols, gens_host[:m])
+    cdt = time.perf_counter() - t0
+    entry["cpu_baseline"] = {
+        "value": 3 * m / cdt, "unit": "row-output ops/s", "cores": 1, "kind": "reference",
+        "sample": f"3 outputs (8-, 32-, 256-bit) x 2^14 rows through the reference's variable-base "
+                  f"CPU backend, {cdt:.2f} s on 1 core (its fixed-base path needs CUDA headers; a "
+                  "w = 16 table for 2^18 generators would be 64 GiB)"}
+    return entry
+
+
+def run_configs(lib, oracle, args, dev, stream):
+    entries = [config1(oracle)]
+    if oracle is None:
+        return entries
+    s3 = torch.from_numpy(wl.mt19937_scalars(1, 1 << 22, 32, top_mask=0x0f)).to(dev)
+    e3 = variable_base_config(lib, oracle, 1, "3: bls12-381 G1 MSM, n = 2^22, 252-bit scalars", 22,
+                              1, s3, args.config_steps, dev, stream, 15)
+    e3["data"] = "mt19937{0} bytes, top nibble masked; generators g_i = (i + 1) G"
+    entries.append(e3)
+    del s3
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    s4 = torch.randint(0, 256, (256, 1 << 20, 32), dtype=torch.uint8, device=dev, generator=g)
+    s4[:, :, 31] &= 0x0f
+    e4 = variable_base_config(lib, oracle, 2, "4: bn254 G1 multi-commitment, 256 columns x 2^20 "
+                              "rows (the whole config on ONE GPU)", 20, 256, s4, args.config_steps,
+                              dev, stream, 15)
+    e4["data"] = "torch device generator (2^33 draws of a serial mt19937 take 215 s); g_i = (i + 1) G"
+    entries.append(e4)
+    del s4
+    torch.cuda.empty_cache()
+    entries.append(config5(lib, oracle, args.config_steps, dev, stream))
+    return entries
+
+
+def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist):
+    """N > 1: config 4's 256 columns sharded over the ranks (strong scaling), one all-gather of
+    the 72-byte commitments"""
+    cid, n, columns = 2, 1 << 20, 256
+    per = columns // world
+    begin = rank * per
+    g = torch.Generator(device=dev)
+    g.manual_seed(4000 + rank)
+    scalars = torch.randint(0, 256, (per, n, 32), dtype=torch.uint8, device=dev, generator=g)
+    scalars[:, :, 31] &= 0x0f
+    base, gens = wl.dlog_generators(lib, oracle, cid, n, dev, stream)
+    out = torch.zeros((per, 72), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world * per, 72), dtype=torch.uint8, device=dev)
+    desc = (api.sxt_sequence_descriptor * per)()
+    for c in range(per):
+        desc[c] = api.sxt_sequence_descriptor(32, n, scalars[c].data_ptr(), 0)
+
+    def step():
+        lib.bzamd_msm_device(cid, vp(out), per, desc, vp(gens), stream)
+        dist.all_gather_into_tensor(gathered, out)
+
+    step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.config_steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item()) / args.config_steps
+    # every rank checks its own shard inside the gathered result
+    got = gathered.cpu().numpy()[begin:begin + per]
+    ok = True
+    for c in range(per):
+        sums = wl.weighted_byte_sums(scalars[c])
+        want = wl.expected_canonical(oracle, cid, base, wl.weighted_scalar_sum(sums, 0, 32))
+        ok = ok and np.array_equal(got[c], want[:72])
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    assert int(flag.item()) == 1, "sharded config 4: a commitment differs from the reference"
+    ops = world * per * n
+    return {"config": f"4: bn254 G1, {world * per} columns x 2^20 rows sharded over {world} GPUs "
+                      "(RCCL all-gather of the commitments)", "scaling": "strong",
+            "columns_per_gpu": per, "ms_per_call": dt * 1e3, "scalar_point_ops_per_s": ops / dt,
+            "commitments_per_s": world * per / dt,
+            "verified": "every rank's commitments bit-exact vs the reference's curve code"}
+
+
+#--------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,28 +357,29 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+    # one process per GPU: the library's own multi-device sharding stays off, this process drives
+    # the device torch selected
+    os.environ["BLITZAR_AMD_NUM_DEVICES"] = "1"
 
-    name = "curve25519_msm_n2^20_252bit"
-    curve_id, log2n, nbytes, top_mask, gen_bytes = WORKLOADS[name]
-    if args.log2n is not None:
-        log2n = args.log2n
+    curve_id, nbytes, top_mask, gen_bytes = api.SXT_CURVE_RISTRETTO255, 32, 0x0f, 160
+    log2n = 20 if args.log2n is None else args.log2n
     n = 1 << log2n
+    name = f"curve25519_msm_n2^{log2n}_252bit"
 
     lib = api.load()
     assert api.init(api.SXT_GPU_BACKEND, 0) == 0
-    stream = torch.cuda.current_stream()
-    sh = ctypes.c_void_p(stream.cuda_stream)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    oracle = None if args.no_cpu_baseline else load_oracle()
 
-    # synthetic inputs, resident in HBM: per-rank scalar column, shared generator set
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    scalars = torch.randint(0, 256, (n, nbytes), dtype=torch.uint8, device=dev, generator=g)
-    scalars[:, nbytes - 1] &= top_mask
+    # synthetic inputs, resident in HBM: per-rank scalar column (mt19937{rank}), shared generators
+    scalars_host = wl.mt19937_scalars(1, n, nbytes, top_mask=top_mask, seed=rank)[0]
+    scalars = torch.from_numpy(scalars_host).to(dev)
     generators = torch.empty((n, gen_bytes), dtype=torch.uint8, device=dev)
-    lib.bzamd_ristretto255_generators_device(ctypes.c_void_p(generators.data_ptr()), 0, n, sh)
+    lib.bzamd_ristretto255_generators_device(vp(generators), 0, n, stream)
     out = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
     gathered = torch.zeros((world, 32), dtype=torch.uint8, device=dev)
     desc = (api.sxt_sequence_descriptor * 1)()
@@ -120,8 +387,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, desc,
-                             ctypes.c_void_p(generators.data_ptr()), sh)
+        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
         if world > 1:
             dist.all_gather_into_tensor(gathered, out)
 
@@ -131,7 +397,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    lib.bzamd_stage_timing_begin(args.steps)
+    clock = StageClock(lib, args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -140,29 +406,54 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    stage_ms = (ctypes.c_double * 6)()
-    calls = lib.bzamd_stage_timing_collect(stage_ms)
+    per_call, calls = clock.collect(args.steps)
+    timed_output = out.cpu().numpy().copy()
 
-    # informational second leg (rank 0 of a single-GPU run): the same step with the generators
-    # registered once as a resident set (bzamd_generators_*), i.e. without the
-    # per-call conversion of caller generators.  Never used for `value`.
+    # informational second leg (single-GPU run): the same step with the generators registered once
+    # as a resident set (bzamd_generators_*).  Never used for `value`.
     resident_ms = None
     if world == 1:
-        handle = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(generators.data_ptr()), n, sh)
+        handle = lib.bzamd_generators_new_device(curve_id, vp(generators), n, stream)
+        out2 = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
         for _ in range(args.warmup):
-            lib.bzamd_msm_device_resident(ctypes.c_void_p(out.data_ptr()), 1, desc, handle, sh)
+            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            lib.bzamd_msm_device_resident(ctypes.c_void_p(out.data_ptr()), 1, desc, handle, sh)
+            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
         torch.cuda.synchronize()
         resident_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        assert np.array_equal(out2.cpu().numpy(), timed_output), "resident path disagrees"
         lib.bzamd_generators_free(handle)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # every rank checks the commitment it timed against the reference CPU backend on the same
+    # scalars (the ranks run their 16 s of oracle in parallel); rank 0 / N = 1 reports it as the
+    # CPU baseline
+    cpu = None
+    verified = None
+    if oracle is not None:
+        gens_host = oracle.ristretto_generators(n)
+        t2 = time.perf_counter()
+        want = oracle.commit(0, [(scalars_host, False)], gens_host)
+        cdt = time.perf_counter() - t2
+        assert np.array_equal(want, timed_output), \
+            f"rank {rank}: the timed GPU commitment differs from the reference CPU backend"
+        verified = "timed output bit-exact vs the reference CPU backend on the same scalars"
+        cpu = {"value": n / cdt, "unit": "scalar-point ops/s", "cores": 1, "kind": "reference",
+               "sample": f"the full workload of one step: 1 column x 2^{log2n} rows of the same "
+                         f"mt19937 scalars and generators, {cdt:.2f} s on 1 of {os.cpu_count()} "
+                         "host cores (the reference cpu backend is single-threaded; N independent "
+                         "processes scale it by the core count)",
+               "all_cores_estimate": n / cdt * (os.cpu_count() or 1)}
+
+    sharded = None
+    if world > 1 and oracle is not None and not args.no_configs and 256 % world == 0:
+        sharded = sharded_config4(lib, oracle, args, dev, stream, rank, world, dist)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -180,62 +471,59 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 limbs (9 x 29-bit GF(2^255-19), v_mad_u64_u32 products)",
-            "data": "synthetic: uniform random 252-bit scalars, built-in ristretto generators",
-            "config": {"workload": name if args.log2n is None else f"curve25519_msm_n2^{log2n}_252bit",
-                       "columns_per_gpu": 1, "rows": n, "parallelism": f"columns x{world}"},
+            "data": "synthetic: std::mt19937{rank} bytes, uniform 252-bit scalars, generators "
+                    "compute_base_element(i) supplied by the caller on every call",
+            "config": {"workload": name, "columns_per_gpu": 1, "rows": n,
+                       "parallelism": f"columns x{world}"},
         }
+        if verified:
+            result["verified"] = verified
         if resident_ms is not None:
             result["resident_generators_ms_per_step"] = resident_ms
         if calls > 0:
-            per_call = {STAGES[i]: stage_ms[i] / calls for i in range(6)}
             result["stage_ms"] = {k: round(v, 4) for k, v in per_call.items()}
-            # dominant kernel: k_accumulate.  Algorithmic bytes per launch = SURVEY 8(d) per-unit
-            # figure (scalar + generator bytes per scalar-point op) x ops per launch.
             alg_bytes = n * (nbytes + gen_bytes)
             dur_s = per_call["accumulate"] * 1e-3
-            achieved = alg_bytes / dur_s / 1e9
+            roof = roofline_of("k_accumulate<ed25519>", alg_bytes, per_call["accumulate"])
+            roof["algorithmic_bytes_per_launch"] = alg_bytes
+            roof["kernel_ms"] = per_call["accumulate"]
             # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command
             # (tools/prof/run_pmc.sh -> profiles/roofline_traffic.json); null until collected
-            traffic = None
-            valu_busy = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath) and args.log2n is None:
                 with open(tpath) as fh:
                     pmc = json.load(fh)
-                traffic = pmc.get("k_accumulate_bytes_per_launch")
-                valu_busy = pmc.get("valu_busy")
-            result["roofline"] = {
-                "kernel": "k_accumulate<ed25519>",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms": per_call["accumulate"],
-                # the binding bound of this kernel is integer issue, not HBM:
-                # fraction of cycles the SIMDs' VALU was issuing, from the same PMC run
-                "valu_busy": valu_busy,
-            }
+                roof["traffic"] = pmc.get("k_accumulate_bytes_per_launch")
+                roof["traffic_source"] = pmc.get("source", "profiles/roofline_traffic.json")
+                roof["valu_busy"] = pmc.get("valu_busy")
+            cal = alu_calibration()
+            clock_hz = cal.get("effective_clock_hz", EFFECTIVE_CLOCK_HZ)
+            issue = cal.get("mad_u64_u32_cycles", MAD_ISSUE_CYCLES)
+            form = lib.bzamd_accumulate_form() if hasattr(lib, "bzamd_accumulate_form") else 0
+            mads = MADS_PER_ADDITION["niels" if form == 1 else "cached"]
             # one addition per non-zero digit: 252-bit scalars populate ceil(252 / 16) = 16 windows
             additions = n * ((8 * nbytes - (8 - top_mask.bit_length()) + 15) // 16)
-            wave_mads = additions * MADS_PER_ADDITION / 64
-            result["roofline"]["alu"] = {
-                "instruction": "v_mad_u64_u32",
-                "wave_instructions_per_launch": wave_mads,
-                "achieved_per_s": wave_mads / dur_s,
-                "peak_per_s": PEAK_WAVE_MADS_PER_S,
-                "frac": wave_mads / dur_s / PEAK_WAVE_MADS_PER_S,
-            }
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_log2n)
-            if cb is not None:
-                result["cpu_baseline"] = cb
+            wave_mads = additions * mads / 64
+            peak = SIMDS * clock_hz / issue
+            roof["alu"] = {"instruction": "v_mad_u64_u32", "per_addition": mads,
+                           "wave_instructions_per_launch": wave_mads,
+                           "achieved_per_s": wave_mads / dur_s, "peak_per_s": peak,
+                           "issue_cycles": issue, "effective_clock_hz": clock_hz,
+                           "frac": wave_mads / dur_s / peak}
+            result["roofline"] = roof
+        if cpu is not None and world == 1:
+            result["cpu_baseline"] = cpu
+        if world == 1 and not args.no_configs and args.log2n is None:
+            result["configs"] = run_configs(lib, oracle, args, dev, stream)
+        if sharded is not None:
+            result["configs"] = [sharded]
         print(json.dumps(result), flush=True)
+    elif world == 1:
+        pass
 
     api.reset_for_testing()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

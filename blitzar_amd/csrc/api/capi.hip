@@ -13,6 +13,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "blitzar_amd/csrc/api/state.h"
@@ -33,26 +34,34 @@ api_state& state() {
   return *g_state;
 }
 
+// built-in generators: raw p3 copies on the host (served by sxt_ristretto255_get_generators, feed
+// the one-commit chain) and resident addends on EVERY device the backend drives
 void init_host_generators(api_state& st, u64 n) {
   st.host_generators.resize(n);
   st.host_one_commits.resize(n);
   if (n == 0) return;
   if (st.backend == SXT_GPU_BACKEND) {
-    // derive on the device (reference K15), keep both the raw p3 copy (served by
-    // sxt_ristretto255_get_generators) and the resident addends
+    // derive on the device (reference K15)
     BZ_RELEASE_ASSERT(curve25519_vtable().addend_size == sizeof(ed29_cached_packed),
                       "built-in generator derivation and MSM engine disagree on the addend layout");
-    ed_point* d_raw = nullptr;
-    BZ_HIP_CHECK(hipMalloc(&d_raw, sizeof(ed_point) * n));
-    BZ_HIP_CHECK(hipMalloc(&st.d_builtin_addends, curve25519_vtable().resident_addend_size * n));
-    builtin_generators_enqueue(d_raw, 0, n, st.stream);
-    g_kernel_launches += 1;
-    curve25519_vtable().prepare_resident(st.d_builtin_addends, d_raw, n, st.stream);
-    g_kernel_launches += 1;
-    BZ_HIP_CHECK(hipMemcpyAsync(st.host_generators.data(), d_raw, sizeof(ed_point) * n,
-                                hipMemcpyDeviceToHost, st.stream));
-    BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
-    BZ_HIP_CHECK(hipFree(d_raw));
+    for (auto& dsp : st.devices) {
+      device_state& ds = *dsp;
+      ds.activate();
+      ed_point* d_raw = nullptr;
+      BZ_HIP_CHECK(hipMalloc(&d_raw, sizeof(ed_point) * n));
+      BZ_HIP_CHECK(hipMalloc(&ds.d_builtin_addends, curve25519_vtable().resident_addend_size * n));
+      builtin_generators_enqueue(d_raw, 0, n, ds.stream);
+      g_kernel_launches += 1;
+      curve25519_vtable().prepare_resident(ds.d_builtin_addends, d_raw, n, ds.stream);
+      g_kernel_launches += 1;
+      if (ds.slot == 0) {
+        BZ_HIP_CHECK(hipMemcpyAsync(st.host_generators.data(), d_raw, sizeof(ed_point) * n,
+                                    hipMemcpyDeviceToHost, ds.stream));
+      }
+      BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+      BZ_HIP_CHECK(hipFree(d_raw));
+    }
+    st.primary().activate();
   } else {
     for (u64 i = 0; i < n; ++i) st.host_generators[i] = ed::base_element(i);
   }
@@ -76,13 +85,15 @@ void host_builtin_generators(api_state& st, ed_point* out, u64 n, u64 offset) {
   if (done == n) return;
   const u64 first = offset + done, rest = n - done;
   if (st.backend == SXT_GPU_BACKEND) {
-    st.io.reset(sizeof(ed_point) * rest + 256, st.stream);
-    ed_point* d = st.io.take<ed_point>(rest);
-    builtin_generators_enqueue(d, first, rest, st.stream);
+    device_state& ds = st.primary();
+    ds.activate();
+    ds.io.reset(sizeof(ed_point) * rest + 256, ds.stream);
+    ed_point* d = ds.io.take<ed_point>(rest);
+    builtin_generators_enqueue(d, first, rest, ds.stream);
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipMemcpyAsync(out + done, d, sizeof(ed_point) * rest, hipMemcpyDeviceToHost,
-                                st.stream));
-    BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
+                                ds.stream));
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
   } else {
     for (u64 i = 0; i < rest; ++i) out[done + i] = ed::base_element(first + i);
   }
@@ -95,7 +106,9 @@ struct checked_columns {
 };
 
 // reference: populate_exponent_sequence, cbindings/pedersen.cc:44-68 (+ the signed-width rule of
-// sxt/multiexp/pippenger/exponent_aggregates_computation.cc:99-101)
+// sxt/multiexp/pippenger/exponent_aggregates_computation.cc:99-101).  One documented narrowing:
+// the engine indexes rows with 31 bits (32-bit sorted entries = row | sign << 31), so a sequence
+// is limited to 2^31 - 1 rows (69 GB of 32-byte scalars; INTEGRATION.md "Limits").
 checked_columns check_descriptors(const sxt_sequence_descriptor* descriptors, u32 num_sequences) {
   BZ_RELEASE_ASSERT(descriptors != nullptr, "descriptors is null");
   checked_columns r;
@@ -117,6 +130,169 @@ checked_columns check_descriptors(const sxt_sequence_descriptor* descriptors, u3
 
 enum class generator_source { host_api, builtin };
 
+struct generator_ref {
+  generator_source source;
+  const void* host_generators; // host_api: C-ABI layout, first generator of the range
+  u64 offset;                  // builtin: index of the first generator
+};
+
+//--------------------------------------------------------------------------------------------------
+// multi-device plumbing
+//--------------------------------------------------------------------------------------------------
+struct unit_range {
+  size_t begin, end;
+};
+
+// contiguous split of weighted units into `parts` ranges of near-equal weight (some may be empty)
+std::vector<unit_range> split_by_weight(const std::vector<double>& weight, size_t parts) {
+  std::vector<unit_range> r(parts);
+  double total = 0;
+  for (double w : weight) total += w;
+  size_t at = 0;
+  double prefix = 0;
+  for (size_t p = 0; p < parts; ++p) {
+    r[p].begin = at;
+    const double goal = total * static_cast<double>(p + 1) / static_cast<double>(parts);
+    while (at < weight.size() && (p + 1 == parts || prefix + weight[at] / 2 < goal)) {
+      prefix += weight[at];
+      ++at;
+    }
+    r[p].end = at;
+  }
+  return r;
+}
+
+// work of a column in bucket additions (rows x windows), the unit the engine's time follows
+std::vector<double> column_weights(const std::vector<host_column>& cols) {
+  std::vector<double> weight(cols.size());
+  for (size_t i = 0; i < cols.size(); ++i) {
+    weight[i] = static_cast<double>(cols[i].n) * ((cols[i].bit_width + 15) / 16) + 1.0;
+  }
+  return weight;
+}
+
+// a row split gives every shard at least 1024 rows
+size_t row_split_parts(size_t shards, u64 longest) {
+  return static_cast<size_t>(std::min<u64>(shards, std::max<u64>(1, longest / 1024)));
+}
+
+// rows [row_begin, row_end) of every column (columns shorter than the range keep what they have)
+std::vector<host_column> row_range_of(const std::vector<host_column>& cols, u64 row_begin,
+                                      u64 row_end) {
+  std::vector<host_column> mine = cols;
+  for (auto& c : mine) {
+    const u64 b = std::min<u64>(row_begin, c.n), e = std::min<u64>(row_end, c.n);
+    c.data = c.data == nullptr ? nullptr : c.data + b * c.row_stride;
+    c.n = e - b;
+  }
+  return mine;
+}
+
+// fn(k) for k < count, fn(0) on the calling thread and every other k on its own host thread (each
+// thread makes its device current itself); returns when all have finished
+template <class F> void run_on_devices(size_t count, F&& fn) {
+  std::vector<std::thread> workers;
+  workers.reserve(count);
+  for (size_t k = 1; k < count; ++k) workers.emplace_back([&fn, k] { fn(k); });
+  fn(0);
+  for (auto& t : workers) t.join();
+}
+
+// bytes of scalars below which a call stays on one device (threads + extra synchronisations cost
+// ~0.1 ms); tests lower it to force the sharded paths on small inputs
+std::atomic<u64> g_shard_min_bytes{u64{1} << 20};
+
+// Enqueue the commitment of `cols` (HOST column pointers) on one device: stage operands into the
+// device's io arena, run the engine, leave the results in the arena.  Returns the device pointer of
+// the `cols.size()` results (`out_stride` apart); nothing is synchronised.  The columns are
+// uploaded in chunks on a copy stream while the engine works on the previous chunk (the DMA
+// engines and the CUs are independent): the reference benchmark's 10 x 2^20 x 32-byte job spends a
+// third of its time in H2D copies otherwise.
+u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
+                        std::vector<host_column> cols, u64 longest, const generator_ref& gens,
+                        u32 out_stride, bool projective_out, std::vector<hipEvent_t>& events) {
+  ds.activate();
+  size_t total_bytes = 0;
+  for (const auto& c : cols) {
+    total_bytes += device_arena::padded(static_cast<size_t>(c.n) * c.row_stride + 32);
+  }
+  const size_t gen_bytes = gens.source == generator_source::host_api
+                               ? device_arena::padded(vt.api_generator_size * longest + 32) +
+                                     device_arena::padded(vt.addend_size * (longest + 1))
+                               : device_arena::padded(vt.addend_size * (longest + 1));
+  const size_t out_bytes = device_arena::padded(static_cast<size_t>(out_stride) * cols.size());
+  ds.io.reset(total_bytes + gen_bytes + out_bytes + 1024, ds.stream);
+  if (ds.copy_stream == nullptr) {
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&ds.copy_stream, hipStreamNonBlocking));
+  }
+  auto signal = [&](hipStream_t from, hipStream_t to) {
+    hipEvent_t e;
+    BZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    BZ_HIP_CHECK(hipEventRecord(e, from));
+    BZ_HIP_CHECK(hipStreamWaitEvent(to, e, 0));
+    events.push_back(e);
+  };
+  // the io arena may have been reallocated on ds.stream: order the copy stream behind it
+  signal(ds.stream, ds.copy_stream);
+
+  const void* d_addends = nullptr;
+  bool resident = false;
+  if (gens.source == generator_source::host_api) {
+    u8* d_api = ds.io.take<u8>(vt.api_generator_size * longest + 32);
+    void* prepared = ds.io.take<u8>(vt.addend_size * (longest + 1));
+    if (longest > 0) {
+      BZ_HIP_CHECK(hipMemcpyAsync(d_api, gens.host_generators, vt.api_generator_size * longest,
+                                  hipMemcpyHostToDevice, ds.copy_stream));
+      signal(ds.copy_stream, ds.stream);
+      vt.prepare_addends(prepared, d_api, longest, ds.stream);
+      g_kernel_launches += 1;
+    }
+    d_addends = prepared;
+  } else if (gens.offset <= st.host_generators.size() &&
+             longest <= st.host_generators.size() - gens.offset &&
+             ds.d_builtin_addends != nullptr) {
+    d_addends = static_cast<const char*>(ds.d_builtin_addends) +
+                vt.resident_addend_size * gens.offset;
+    resident = true;
+  } else {
+    // beyond the init-time cache: derived on the fly for any offset, like the reference
+    // (precomputed_generators.cc:56-91)
+    ed29_cached_packed* d = ds.io.take<ed29_cached_packed>(longest + 1);
+    builtin_addends_enqueue(d, gens.offset, longest, ds.stream);
+    g_kernel_launches += 1;
+    d_addends = d;
+  }
+  u8* d_out = ds.io.take<u8>(static_cast<size_t>(out_stride) * cols.size());
+
+  constexpr size_t kChunkBytes = size_t{48} << 20;
+  for (size_t begin = 0; begin < cols.size();) {
+    size_t end = begin, bytes_in_chunk = 0;
+    while (end < cols.size() && (end == begin || bytes_in_chunk < kChunkBytes)) {
+      host_column& col = cols[end];
+      if (col.n == 0) {
+        col.data = nullptr;
+      } else {
+        const size_t bytes = static_cast<size_t>(col.n) * col.row_stride;
+        u8* d = ds.io.take<u8>(bytes + 32);
+        BZ_HIP_CHECK(hipMemcpyAsync(d, col.data, bytes, hipMemcpyHostToDevice, ds.copy_stream));
+        col.data = d;
+        bytes_in_chunk += bytes;
+      }
+      ++end;
+    }
+    signal(ds.copy_stream, ds.stream);
+    const std::vector<host_column> chunk(cols.begin() + begin, cols.begin() + end);
+    u8* out_k = d_out + begin * static_cast<size_t>(out_stride);
+    if (resident) {
+      vt.msm_resident(*ds.ctx, out_k, out_stride, projective_out, chunk, d_addends, ds.stream);
+    } else {
+      vt.msm(*ds.ctx, out_k, out_stride, projective_out, chunk, d_addends, nullptr, ds.stream);
+    }
+    begin = end;
+  }
+  return d_out;
+}
+
 // the Pedersen path of all five entry points
 void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequences,
                          const sxt_sequence_descriptor* descriptors, const void* generators,
@@ -127,101 +303,150 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
   api_state& st = state();
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   const u32 out_stride = static_cast<u32>(projective_out ? vt.projective_size : vt.output_size);
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+
+  size_t scalar_bytes = 0;
+  for (const auto& c : cc.cols) scalar_bytes += static_cast<size_t>(c.n) * c.row_stride;
+  u8* out = static_cast<u8*>(commitments);
 
   if (st.backend == SXT_CPU_BACKEND) {
     std::vector<ed_point> builtin;
-    const void* gens = generators;
+    const u8* gens = static_cast<const u8*>(generators);
     if (source == generator_source::builtin) {
       builtin.resize(cc.longest);
       host_builtin_generators(st, builtin.data(), cc.longest, offset_generators);
-      gens = builtin.data();
+      gens = reinterpret_cast<const u8*>(builtin.data());
     }
-    vt.msm_host(static_cast<u8*>(commitments), out_stride, projective_out, cc.cols, gens, false,
-                cc.longest);
+    // BLITZAR_AMD_FORCE_SHARDS on the host backend: the same split rules as the GPU backend below,
+    // one host thread per shard (GPU-less coverage of the sharding logic; the reference cpu
+    // backend is single-threaded)
+    const size_t shards = st.host_shards;
+    if (shards < 2 || projective_out || scalar_bytes < g_shard_min_bytes.load() ||
+        cc.longest == 0) {
+      vt.msm_host(out, out_stride, projective_out, cc.cols, gens, false, cc.longest);
+    } else if (num_sequences >= shards) {
+      const std::vector<unit_range> ranges = split_by_weight(column_weights(cc.cols), shards);
+      run_on_devices(shards, [&](size_t k) {
+        const unit_range r = ranges[k];
+        if (r.begin == r.end) return;
+        const std::vector<host_column> mine(cc.cols.begin() + r.begin, cc.cols.begin() + r.end);
+        u64 longest = 0;
+        for (const auto& c : mine) longest = std::max<u64>(longest, c.n);
+        vt.msm_host(out + r.begin * static_cast<size_t>(out_stride), out_stride, false, mine, gens,
+                    false, longest);
+      });
+    } else {
+      const size_t parts = row_split_parts(shards, cc.longest);
+      const size_t psize = vt.projective_size;
+      std::vector<u8> partials(psize * num_sequences * parts);
+      run_on_devices(parts, [&](size_t k) {
+        const u64 row_begin = cc.longest * k / parts, row_end = cc.longest * (k + 1) / parts;
+        const std::vector<host_column> mine = row_range_of(cc.cols, row_begin, row_end);
+        vt.msm_host(partials.data() + psize * num_sequences * k, static_cast<u32>(psize), true,
+                    mine, gens + vt.api_generator_size * row_begin, false, row_end - row_begin);
+      });
+      vt.fold_encode_host(out, partials.data(), static_cast<u32>(parts), num_sequences);
+    }
     return;
   }
 
-  // GPU backend: stage host operands into the io arena, run, copy the encodings back.  The
-  // columns are uploaded in chunks on a copy stream while the engine works on the previous chunk
-  // (the DMA engines and the CUs are independent): the reference benchmark's 10 x 2^20 x 32-byte
-  // job spends a third of its time in H2D copies otherwise.
-  st.activate();
-  const size_t gen_bytes = source == generator_source::host_api
-                               ? device_arena::padded(vt.api_generator_size * cc.longest + 32) +
-                                     device_arena::padded(vt.addend_size * (cc.longest + 1))
-                               : device_arena::padded(vt.addend_size * (cc.longest + 1));
-  const size_t out_bytes = device_arena::padded(static_cast<size_t>(out_stride) * num_sequences);
-  st.io.reset(cc.total_bytes + gen_bytes + out_bytes + 1024, st.stream);
-  if (st.copy_stream == nullptr) {
-    BZ_HIP_CHECK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking));
-  }
-  std::vector<hipEvent_t> events;
-  auto signal = [&](hipStream_t from, hipStream_t to) {
-    hipEvent_t e;
-    BZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    BZ_HIP_CHECK(hipEventRecord(e, from));
-    BZ_HIP_CHECK(hipStreamWaitEvent(to, e, 0));
-    events.push_back(e);
-  };
-  // the io arena may have been reallocated on st.stream: order the copy stream behind it
-  signal(st.stream, st.copy_stream);
+  // GPU backend.  One device: stage, run, copy back.  Several devices:
+  //   * at least as many columns as devices: contiguous column ranges of near-equal work per
+  //     device, every device needs the generators of its longest column; the encodings go straight
+  //     from each device to the caller's (host) array -- no inter-device traffic at all;
+  //   * fewer columns (one long column): every device takes a row range of every column and the
+  //     matching generator slice, produces projective partials, the partials travel to device 0
+  //     over xGMI (hipMemcpyPeerAsync, <= 160 B per column and device), device 0 folds and encodes
+  //     (k_fold_encode).  Group addition is exact, so the canonical result is the same.
+  const size_t num_devices = st.devices.size();
+  const bool shard = num_devices > 1 && scalar_bytes >= g_shard_min_bytes.load() && cc.longest > 0;
+  const generator_ref all_gens{source, generators, offset_generators};
 
-  const void* d_addends = nullptr;
-  bool resident = false;
-  if (source == generator_source::host_api) {
-    u8* d_api = st.io.take<u8>(vt.api_generator_size * cc.longest + 32);
-    void* prepared = st.io.take<u8>(vt.addend_size * (cc.longest + 1));
-    if (cc.longest > 0) {
-      BZ_HIP_CHECK(hipMemcpyAsync(d_api, generators, vt.api_generator_size * cc.longest,
-                                  hipMemcpyHostToDevice, st.copy_stream));
-      signal(st.copy_stream, st.stream);
-      vt.prepare_addends(prepared, d_api, cc.longest, st.stream);
-      g_kernel_launches += 1;
-    }
-    d_addends = prepared;
-  } else if (offset_generators + cc.longest <= st.host_generators.size() &&
-             st.d_builtin_addends != nullptr) {
-    d_addends = static_cast<const char*>(st.d_builtin_addends) +
-                vt.resident_addend_size * offset_generators;
-    resident = true;
-  } else {
-    ed29_cached_packed* d = st.io.take<ed29_cached_packed>(cc.longest + 1);
-    builtin_addends_enqueue(d, offset_generators, cc.longest, st.stream);
-    g_kernel_launches += 1;
-    d_addends = d;
+  if (!shard) {
+    device_state& ds = st.primary();
+    std::vector<hipEvent_t> events;
+    u8* d_out = enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
+                                    projective_out, events);
+    BZ_HIP_CHECK(hipMemcpyAsync(out, d_out, static_cast<size_t>(out_stride) * num_sequences,
+                                hipMemcpyDeviceToHost, ds.stream));
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+    for (auto& e : events) (void)hipEventDestroy(e);
+    return;
   }
-  u8* d_out = st.io.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
 
-  constexpr size_t kChunkBytes = size_t{48} << 20;
-  for (size_t begin = 0; begin < cc.cols.size();) {
-    size_t end = begin, bytes_in_chunk = 0;
-    while (end < cc.cols.size() && (end == begin || bytes_in_chunk < kChunkBytes)) {
-      host_column& col = cc.cols[end];
-      if (col.n == 0) {
-        col.data = nullptr;
-      } else {
-        const size_t bytes = static_cast<size_t>(col.n) * col.row_stride;
-        u8* d = st.io.take<u8>(bytes + 32);
-        BZ_HIP_CHECK(hipMemcpyAsync(d, col.data, bytes, hipMemcpyHostToDevice, st.copy_stream));
-        col.data = d;
-        bytes_in_chunk += bytes;
-      }
-      ++end;
-    }
-    signal(st.copy_stream, st.stream);
-    const std::vector<host_column> chunk(cc.cols.begin() + begin, cc.cols.begin() + end);
-    u8* out_k = d_out + begin * static_cast<size_t>(out_stride);
-    if (resident) {
-      vt.msm_resident(*st.ctx, out_k, out_stride, projective_out, chunk, d_addends, st.stream);
+  if (num_sequences >= num_devices) {
+    const std::vector<unit_range> ranges = split_by_weight(column_weights(cc.cols), num_devices);
+    run_on_devices(num_devices, [&](size_t k) {
+      const unit_range r = ranges[k];
+      if (r.begin == r.end) return;
+      device_state& ds = *st.devices[k];
+      std::vector<host_column> mine(cc.cols.begin() + r.begin, cc.cols.begin() + r.end);
+      u64 longest = 0;
+      for (const auto& c : mine) longest = std::max<u64>(longest, c.n);
+      std::vector<hipEvent_t> events;
+      u8* d_out = enqueue_commitments(st, ds, vt, std::move(mine), longest, all_gens, out_stride,
+                                      projective_out, events);
+      BZ_HIP_CHECK(hipMemcpyAsync(out + r.begin * static_cast<size_t>(out_stride), d_out,
+                                  static_cast<size_t>(out_stride) * (r.end - r.begin),
+                                  hipMemcpyDeviceToHost, ds.stream));
+      BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+      for (auto& e : events) (void)hipEventDestroy(e);
+    });
+    st.primary().activate();
+    return;
+  }
+
+  // row split
+  const u32 psize = static_cast<u32>(vt.projective_size);
+  const size_t parts = row_split_parts(num_devices, cc.longest);
+  device_state& root = st.primary();
+  root.activate();
+  const size_t partial_bytes = static_cast<size_t>(psize) * num_sequences;
+  st.gather.reset(partial_bytes * parts + device_arena::padded(out_stride * num_sequences) + 512,
+                  root.stream);
+  u8* d_partials = st.gather.take<u8>(partial_bytes * parts);
+  u8* d_final = st.gather.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
+  BZ_HIP_CHECK(hipStreamSynchronize(root.stream)); // the gather buffer exists before peers write
+  run_on_devices(parts, [&](size_t k) {
+    device_state& ds = *st.devices[k];
+    const u64 row_begin = cc.longest * k / parts, row_end = cc.longest * (k + 1) / parts;
+    std::vector<host_column> mine = row_range_of(cc.cols, row_begin, row_end);
+    generator_ref g = all_gens;
+    if (g.source == generator_source::host_api) {
+      g.host_generators = static_cast<const u8*>(generators) + vt.api_generator_size * row_begin;
     } else {
-      vt.msm(*st.ctx, out_k, out_stride, projective_out, chunk, d_addends, nullptr, st.stream);
+      g.offset += row_begin;
     }
-    begin = end;
+    std::vector<hipEvent_t> events;
+    u8* d_part = enqueue_commitments(st, ds, vt, std::move(mine), row_end - row_begin, g, psize,
+                                     true, events);
+    BZ_HIP_CHECK(hipMemcpyPeerAsync(d_partials + partial_bytes * k, root.device, d_part, ds.device,
+                                    partial_bytes, ds.stream));
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+    for (auto& e : events) (void)hipEventDestroy(e);
+  });
+  root.activate();
+  if (projective_out) {
+    vt.fold_device(d_final, d_partials, static_cast<u32>(parts), num_sequences, root.stream);
+  } else {
+    vt.fold_encode_device(d_final, d_partials, static_cast<u32>(parts), num_sequences,
+                          root.stream);
   }
-  BZ_HIP_CHECK(hipMemcpyAsync(commitments, d_out, static_cast<size_t>(out_stride) * num_sequences,
-                              hipMemcpyDeviceToHost, st.stream));
-  BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
-  for (auto& e : events) (void)hipEventDestroy(e);
+  g_kernel_launches += 1;
+  BZ_HIP_CHECK(hipMemcpyAsync(out, d_final, static_cast<size_t>(out_stride) * num_sequences,
+                              hipMemcpyDeviceToHost, root.stream));
+  BZ_HIP_CHECK(hipStreamSynchronize(root.stream));
+}
+
+// a positive count from the environment, `fallback` when unset; anything else aborts
+long env_count(const char* name, long fallback) {
+  const char* val = std::getenv(name);
+  if (val == nullptr || val[0] == 0) return fallback;
+  char* end = nullptr;
+  const long v = std::strtol(val, &end, 10);
+  BZ_RELEASE_ASSERT(end != nullptr && *end == 0 && v >= 1 && v <= 64,
+                    "BLITZAR_AMD_NUM_DEVICES / BLITZAR_AMD_FORCE_SHARDS must be in [1, 64]");
+  return v;
 }
 
 int backend_from_environment(int backend) {
@@ -253,10 +478,43 @@ int sxt_init(const struct sxt_config* config) {
   if (backend == SXT_GPU_BACKEND) {
     // no silent fallback: a GPU backend without a GPU is a hard error, as in the reference
     // (cbindings/backend.cc:61-63 "no supported GPUs found")
-    BZ_RELEASE_ASSERT(device_count() > 0, "no supported GPUs found");
-    BZ_HIP_CHECK(hipGetDevice(&st->device));
-    BZ_HIP_CHECK(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
-    st->ctx = msm_context_new();
+    const int visible = device_count();
+    BZ_RELEASE_ASSERT(visible > 0, "no supported GPUs found");
+    int current = 0;
+    BZ_HIP_CHECK(hipGetDevice(&current));
+    // devices this backend drives (api/state.h): the current one first, then the others
+    std::vector<int> ids;
+    const long forced = env_count("BLITZAR_AMD_FORCE_SHARDS", 0);
+    if (forced > 1) {
+      ids.assign(static_cast<size_t>(forced), current);
+    } else {
+      const long cap = env_count("BLITZAR_AMD_NUM_DEVICES", visible);
+      ids.push_back(current);
+      for (int d = 0; d < visible && static_cast<long>(ids.size()) < cap; ++d) {
+        if (d != current) ids.push_back(d);
+      }
+    }
+    for (size_t k = 0; k < ids.size(); ++k) {
+      auto ds = std::make_unique<device_state>();
+      ds->slot = static_cast<int>(k);
+      ds->device = ids[k];
+      ds->activate();
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
+      ds->ctx = msm_context_new();
+      if (ids[k] != current) {
+        // results of a row-split call travel to device 0 with hipMemcpyPeerAsync
+        int can = 0;
+        BZ_HIP_CHECK(hipDeviceCanAccessPeer(&can, ids[k], current));
+        if (can) {
+          const hipError_t e = hipDeviceEnablePeerAccess(current, 0);
+          if (e != hipSuccess) (void)hipGetLastError(); // already enabled
+        }
+      }
+      st->devices.push_back(std::move(ds));
+    }
+    BZ_HIP_CHECK(hipSetDevice(current));
+  } else {
+    st->host_shards = static_cast<size_t>(env_count("BLITZAR_AMD_FORCE_SHARDS", 1));
   }
   init_host_generators(*st, config->num_precomputed_generators);
   g_state = st.release();
@@ -319,7 +577,7 @@ int sxt_ristretto255_get_generators(struct sxt_ristretto255* generators, uint64_
   api_state& st = state();
   if (num_generators == 0) return 0;
   if (generators == nullptr) return 1;
-  if (st.backend == SXT_GPU_BACKEND) st.activate();
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
   host_builtin_generators(st, reinterpret_cast<ed_point*>(generators), num_generators,
                           offset_generators);
   return 0;
@@ -328,6 +586,7 @@ int sxt_ristretto255_get_generators(struct sxt_ristretto255* generators, uint64_
 int sxt_curve25519_get_one_commit(struct sxt_ristretto255* one_commit, uint64_t n) {
   api_state& st = state();
   BZ_RELEASE_ASSERT(one_commit != nullptr, "one_commit is null");
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
   ed_point r;
   if (n < st.host_one_commits.size()) {
     r = st.host_one_commits[n];
@@ -340,7 +599,6 @@ int sxt_curve25519_get_one_commit(struct sxt_ristretto255* one_commit, uint64_t 
       start = st.host_one_commits.size() - 1;
       r = st.host_one_commits[start];
     }
-    if (st.backend == SXT_GPU_BACKEND) st.activate();
     std::vector<ed_point> gens(n - start);
     host_builtin_generators(st, gens.data(), n - start, start);
     for (const auto& g : gens) r = ed::add(r, g);
@@ -365,18 +623,25 @@ unsigned partition_window_width() {
 void handle_make_resident(multiexp_handle& h) {
   api_state& st = state();
   if (st.backend != SXT_GPU_BACKEND || h.n == 0) return;
-  st.activate();
-  h.device = st.device;
-  void* d_proj = nullptr;
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
   const size_t bytes = h.vt->projective_size * h.n;
-  BZ_HIP_CHECK(hipMalloc(&d_proj, bytes));
-  BZ_HIP_CHECK(hipMalloc(&h.d_addends, h.vt->resident_addend_size * (h.n + 1)));
-  BZ_HIP_CHECK(hipMemcpyAsync(d_proj, h.host_projective.data(), bytes, hipMemcpyHostToDevice,
-                              st.stream));
-  h.vt->prepare_resident_projective(h.d_addends, d_proj, h.n, st.stream);
-  g_kernel_launches += 1;
-  BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
-  BZ_HIP_CHECK(hipFree(d_proj));
+  for (auto& dsp : st.devices) {
+    device_state& ds = *dsp;
+    ds.activate();
+    void* d_proj = nullptr;
+    void* d_addends = nullptr;
+    BZ_HIP_CHECK(hipMalloc(&d_proj, bytes));
+    BZ_HIP_CHECK(hipMalloc(&d_addends, h.vt->resident_addend_size * (h.n + 1)));
+    BZ_HIP_CHECK(hipMemcpyAsync(d_proj, h.host_projective.data(), bytes, hipMemcpyHostToDevice,
+                                ds.stream));
+    h.vt->prepare_resident_projective(d_addends, d_proj, h.n, ds.stream);
+    g_kernel_launches += 1;
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+    BZ_HIP_CHECK(hipFree(d_proj));
+    h.d_addends.push_back(d_addends);
+    h.devices.push_back(ds.device);
+  }
+  st.primary().activate();
 }
 
 // the three fixed-base entry points differ only in how a row is cut into per-output bit fields
@@ -394,6 +659,8 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   for (unsigned k = 0; k < num_outputs; ++k) {
     const unsigned width = bit_table != nullptr ? bit_table[k] : uniform_bits;
     BZ_RELEASE_ASSERT(width > 0, "output bit width must be positive");
+    // documented narrowing (INTEGRATION.md "Limits"): the reference accepts any unsigned width;
+    // here an output is one scalar of at most 256 bits, like every sxt_sequence_descriptor
     BZ_RELEASE_ASSERT(width <= 256, "outputs wider than 256 bits are not supported");
     const unsigned len = lengths != nullptr ? lengths[k] : n;
     BZ_RELEASE_ASSERT(len >= prev_len, "output lengths must be sorted in ascending order");
@@ -406,7 +673,10 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   const u64 row_bytes = (total_bits + 7) / 8;
   BZ_RELEASE_ASSERT(max_len <= h.n, "more rows than generators in the handle");
   BZ_RELEASE_ASSERT(max_len == 0 || scalars != nullptr, "scalars is null");
-  for (auto& c : cols) {
+  std::vector<u64> first_bit(num_outputs);
+  for (unsigned k = 0; k < num_outputs; ++k) {
+    host_column& c = cols[k];
+    first_bit[k] = c.bit_offset;
     c.row_stride = row_bytes;
     // fold whole bytes of the bit offset into the base pointer
     c.data = scalars + (c.bit_offset >> 3);
@@ -414,10 +684,23 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   }
   const u32 out_stride = static_cast<u32>(h.vt->projective_size);
 
+  if (device_operands) {
+    // asynchronous on the caller's stream and device: no shared staging, no api lock
+    BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
+    int dev = 0;
+    BZ_HIP_CHECK(hipGetDevice(&dev));
+    const void* d_addends = h.addends_on(dev);
+    BZ_RELEASE_ASSERT(d_addends != nullptr, "the handle has no addends on the current device");
+    h.vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(res), out_stride, true,
+                       cols, d_addends, caller_stream);
+    return;
+  }
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+
   // BLITZAR_DUMP_DIR: record packed / vlen calls with host operands (the plain byte-aligned entry
   // point is not recorded by the reference either, gpu_backend.cc:257-272)
   std::unique_ptr<dump_recorder> recorder;
-  if (bit_table != nullptr && !device_operands) {
+  if (bit_table != nullptr) {
     recorder = std::make_unique<dump_recorder>(lengths != nullptr ? "vlen-multiexponentiation"
                                                                    : "packed-multiexponentiation");
     if (recorder->recording()) {
@@ -431,33 +714,68 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
     }
   };
 
+  // outputs are independent units -- contiguous output ranges of near-equal work per device
+  // (SURVEY 8(e)); BLITZAR_AMD_FORCE_SHARDS applies the same split to the host backend's threads
+  const size_t num_devices =
+      st.backend == SXT_CPU_BACKEND ? st.host_shards : st.devices.size();
+  const size_t scalar_bytes = static_cast<size_t>(row_bytes) * max_len;
+  const bool shard = num_devices > 1 && num_outputs >= num_devices && max_len > 0 &&
+                     scalar_bytes >= g_shard_min_bytes.load();
+  std::vector<unit_range> ranges{{0, num_outputs}};
+  if (shard) ranges = split_by_weight(column_weights(cols), num_devices);
+  u8* out = static_cast<u8*>(res);
+
   if (st.backend == SXT_CPU_BACKEND) {
-    BZ_RELEASE_ASSERT(!device_operands, "device entry points need the GPU backend");
-    h.vt->msm_host(static_cast<u8*>(res), out_stride, true, cols, h.host_projective.data(), true,
-                   max_len);
+    run_on_devices(ranges.size(), [&](size_t k) {
+      const unit_range r = ranges[k];
+      if (r.begin == r.end) return;
+      const std::vector<host_column> mine(cols.begin() + r.begin, cols.begin() + r.end);
+      u64 rows = 0;
+      for (const auto& c : mine) rows = std::max<u64>(rows, c.n);
+      h.vt->msm_host(out + r.begin * static_cast<size_t>(out_stride), out_stride, true, mine,
+                     h.host_projective.data(), true, rows);
+    });
     record_result();
     return;
   }
-  if (device_operands) {
-    h.vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(res), out_stride, true,
-                       cols, h.d_addends, caller_stream);
-    return;
-  }
-  st.activate();
-  const size_t scalar_bytes = static_cast<size_t>(row_bytes) * max_len;
-  const size_t out_bytes = static_cast<size_t>(out_stride) * num_outputs;
-  st.io.reset(device_arena::padded(scalar_bytes + 64) + device_arena::padded(out_bytes) + 512,
-              st.stream);
-  u8* d_scalars = st.io.take<u8>(scalar_bytes + 64);
-  if (scalar_bytes > 0) {
-    BZ_HIP_CHECK(hipMemcpyAsync(d_scalars, scalars, scalar_bytes, hipMemcpyHostToDevice,
-                                st.stream));
-  }
-  for (auto& c : cols) c.data = d_scalars + (c.data - scalars);
-  u8* d_out = st.io.take<u8>(out_bytes);
-  h.vt->msm_resident(*st.ctx, d_out, out_stride, true, cols, h.d_addends, st.stream);
-  BZ_HIP_CHECK(hipMemcpyAsync(res, d_out, out_bytes, hipMemcpyDeviceToHost, st.stream));
-  BZ_HIP_CHECK(hipStreamSynchronize(st.stream));
+
+  // GPU backend: the outputs of a call are bit fields of the same rows, so a device uploads only
+  // the byte span of every row that its outputs occupy (strided 2-D copy)
+  run_on_devices(ranges.size(), [&](size_t k) {
+    const unit_range r = ranges[k];
+    if (r.begin == r.end) return;
+    device_state& ds = *st.devices[k];
+    ds.activate();
+    std::vector<host_column> mine(cols.begin() + r.begin, cols.begin() + r.end);
+    u64 rows = 0;
+    for (const auto& c : mine) rows = std::max<u64>(rows, c.n);
+    const size_t outputs = r.end - r.begin;
+    const size_t out_bytes = static_cast<size_t>(out_stride) * outputs;
+    // bytes [span_begin, span_end) of every row hold this range's bit fields
+    const u64 span_begin = first_bit[r.begin] >> 3;
+    const u64 last_bit = first_bit[r.end - 1] + cols[r.end - 1].bit_width;
+    const u64 span = (last_bit + 7) / 8 - span_begin;
+    ds.io.reset(device_arena::padded(span * rows + 64) + device_arena::padded(out_bytes) + 512,
+                ds.stream);
+    u8* d_scalars = ds.io.take<u8>(span * rows + 64);
+    if (rows > 0 && span == row_bytes) {
+      BZ_HIP_CHECK(hipMemcpyAsync(d_scalars, scalars, span * rows, hipMemcpyHostToDevice,
+                                  ds.stream));
+    } else if (rows > 0) {
+      BZ_HIP_CHECK(hipMemcpy2DAsync(d_scalars, span, scalars + span_begin, row_bytes, span, rows,
+                                    hipMemcpyHostToDevice, ds.stream));
+    }
+    for (auto& c : mine) {
+      c.data = d_scalars + ((c.data - scalars) - span_begin);
+      c.row_stride = span;
+    }
+    u8* d_out = ds.io.take<u8>(out_bytes);
+    h.vt->msm_resident(*ds.ctx, d_out, out_stride, true, mine, h.d_addends[ds.slot], ds.stream);
+    BZ_HIP_CHECK(hipMemcpyAsync(out + r.begin * static_cast<size_t>(out_stride), d_out, out_bytes,
+                                hipMemcpyDeviceToHost, ds.stream));
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+  });
+  st.primary().activate();
   record_result();
 }
 } // namespace
@@ -500,14 +818,23 @@ void sxt_multiexp_handle_write_to_file(const struct sxt_multiexp_handle* handle,
   BZ_RELEASE_ASSERT(h != nullptr, "handle is null");
   std::FILE* f = std::fopen(filename, "wb");
   BZ_RELEASE_ASSERT(f != nullptr, "failed to open partition table file for writing");
-  h->vt->write_partition_table(f, h->window_width, h->host_projective.data(), h->n);
-  std::fclose(f);
+  const bool ok = h->vt->write_partition_table(f, h->window_width, h->host_projective.data(), h->n);
+  // a full disk must not leave a silently truncated table behind
+  BZ_RELEASE_ASSERT(std::fclose(f) == 0 && ok, "short write to the partition table file");
 }
 
 void sxt_multiexp_handle_free(struct sxt_multiexp_handle* handle) {
   auto* h = reinterpret_cast<multiexp_handle*>(handle);
   if (h == nullptr) return;
-  if (h->d_addends != nullptr) (void)hipFree(h->d_addends);
+  if (!h->d_addends.empty()) {
+    int current = 0;
+    (void)hipGetDevice(&current);
+    for (size_t k = 0; k < h->d_addends.size(); ++k) {
+      (void)hipSetDevice(h->devices[k]);
+      (void)hipFree(h->d_addends[k]);
+    }
+    (void)hipSetDevice(current);
+  }
   delete h;
 }
 
@@ -595,6 +922,14 @@ const char* bzamd_version(void) { return "blitzar_amd 0.1 (gfx950)"; }
 int bzamd_device_count(void) { return device_count(); }
 
 int bzamd_active_backend(void) { return g_state == nullptr ? 0 : g_state->backend; }
+
+int bzamd_num_devices(void) {
+  if (g_state == nullptr) return 0;
+  return static_cast<int>(g_state->backend == SXT_GPU_BACKEND ? g_state->devices.size()
+                                                              : g_state->host_shards);
+}
+
+void bzamd_set_shard_min_bytes(uint64_t bytes) { g_shard_min_bytes.store(bytes); }
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
 

@@ -1,9 +1,23 @@
 // Process-wide backend singleton behind the C ABI (reference: the `backend` pointer of
 // cbindings/backend.cc:37 plus the leaked generator caches of
 // sxt/seqcommit/generator/precomputed_generators.cc:38).
+//
+// The GPU backend drives every visible HIP device from this one process, like the reference's
+// (sxt/execution/device/for_each.cc:56-82 hands chunks to "the next available device",
+// gpu_backend.cc:150-193): one `device_state` per device -- its own stream pair, engine context,
+// staging arena and replica of the resident built-in generators -- and one host thread per device
+// for the duration of a blocking sxt_* call (api/capi.hip).  Knobs, read once at sxt_init:
+//   BLITZAR_AMD_NUM_DEVICES   use at most this many devices (default: all visible; bench.py's
+//                             one-process-per-GPU ranks set 1)
+//   BLITZAR_AMD_FORCE_SHARDS  k > 1: k logical devices on the CURRENT physical device -- the
+//                             multi-device code paths (sharding, threads, peer copies, fold) on a
+//                             one-GPU box, the way the reference's tests force chunking with
+//                             split_options (pippenger2/multiexponentiation.t.cc:150-180)
 #pragma once
 
 #include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "blitzar_amd/csrc/base/device.h"
@@ -13,28 +27,54 @@
 
 namespace bz {
 
-struct api_state {
-  int backend = 0; // SXT_CPU_BACKEND / SXT_GPU_BACKEND
-  int device = 0;  // device current at sxt_init; the blocking sxt_* calls run there
+struct device_state {
+  int slot = 0;   // index into api_state::devices (handles keep one addend replica per slot)
+  int device = 0; // HIP device id
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr; // H2D of the next chunk of columns beside the computation
   msm_context* ctx = nullptr;
-  device_arena io; // staging of host operands / results of the blocking sxt_* calls
+  device_arena io;                   // staging of host operands / results of the blocking calls
+  void* d_builtin_addends = nullptr; // resident addends of the built-in generators (vt layout)
+
+  void activate() const { BZ_HIP_CHECK(hipSetDevice(device)); }
+  ~device_state() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (d_builtin_addends != nullptr) (void)hipFree(d_builtin_addends);
+    if (ctx != nullptr) msm_context_free(ctx);
+    if (copy_stream != nullptr) (void)hipStreamDestroy(copy_stream);
+    if (stream != nullptr) (void)hipStreamDestroy(stream);
+  }
+};
+
+struct api_state {
+  int backend = 0; // SXT_CPU_BACKEND / SXT_GPU_BACKEND
+  // devices[0] is the device that was current at sxt_init: single-device work runs there
+  std::vector<std::unique_ptr<device_state>> devices;
+  // the blocking sxt_* entry points are serialised (the reference tolerates concurrent callers
+  // only because its per-call state is thread_local; here the staging arenas are per device)
+  std::mutex api_mutex;
+  size_t host_shards = 1; // SXT_CPU_BACKEND: host threads a call is split over (FORCE_SHARDS)
+  device_arena gather; // on devices[0]: partial results of the other devices (row-split calls)
 
   // built-in ristretto generators 0 .. num_precomputed-1
   std::vector<ed_point> host_generators;  // raw extended coordinates
   std::vector<ed_point> host_one_commits; // [i] = g_0 + ... + g_{i-1}
-  void* d_builtin_addends = nullptr;       // resident addends of the same generators (vt layout)
 
-  // engine contexts of other devices touched through the device entry points
+  // engine contexts of devices touched only through the device entry points (bzamd_*_device)
+  std::mutex context_mutex;
   std::map<int, msm_context*> device_contexts;
 
-  void activate() const { BZ_HIP_CHECK(hipSetDevice(device)); }
+  device_state& primary() { return *devices[0]; }
 
+  // the context asynchronous device entry points use: the one of the CURRENT device
   msm_context* context_for_current_device() {
     int dev = 0;
     BZ_HIP_CHECK(hipGetDevice(&dev));
-    if (dev == device) return ctx;
+    for (auto& d : devices) {
+      if (d->device == dev) return d->ctx;
+    }
+    std::lock_guard<std::mutex> lock(context_mutex);
     auto it = device_contexts.find(dev);
     if (it != device_contexts.end()) return it->second;
     msm_context* c = msm_context_new();
@@ -44,12 +84,19 @@ struct api_state {
 
   ~api_state() {
     if (backend == 2) {
-      (void)hipDeviceSynchronize();
-      if (d_builtin_addends != nullptr) (void)hipFree(d_builtin_addends);
-      if (ctx != nullptr) msm_context_free(ctx);
-      for (auto& kv : device_contexts) msm_context_free(kv.second);
-      if (copy_stream != nullptr) (void)hipStreamDestroy(copy_stream);
-      if (stream != nullptr) (void)hipStreamDestroy(stream);
+      int current = 0;
+      (void)hipGetDevice(&current);
+      if (!devices.empty()) {
+        (void)hipSetDevice(devices[0]->device);
+        gather.release();
+      }
+      devices.clear();
+      for (auto& kv : device_contexts) {
+        (void)hipSetDevice(kv.first);
+        (void)hipDeviceSynchronize();
+        msm_context_free(kv.second);
+      }
+      (void)hipSetDevice(current);
     }
   }
 };

@@ -82,6 +82,12 @@ public:
 
   static size_t padded(size_t bytes) { return (bytes + 255) & ~size_t{255}; }
   size_t capacity() const { return capacity_; }
+  // give the memory back now (the owning device must be current)
+  void release() {
+    if (base_ != nullptr) (void)hipFree(base_);
+    base_ = nullptr;
+    capacity_ = used_ = 0;
+  }
 
 private:
   void* base_ = nullptr;

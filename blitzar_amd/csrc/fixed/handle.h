@@ -16,7 +16,15 @@ struct multiexp_handle {
   u64 n = 0;                 // generators (file-loaded handles include the identity padding)
   unsigned window_width = 16; // only used when the handle is written to a file
   std::vector<u8> host_projective; // n projective elements (host copy)
-  void* d_addends = nullptr;       // GPU backend: resident addends
-  int device = 0;
+  // GPU backend: resident addends, one replica per device the backend drives (indexed by
+  // device_state::slot; 16 MiB for 2^18 Grumpkin generators)
+  std::vector<void*> d_addends;
+  std::vector<int> devices;
+  const void* addends_on(int device) const {
+    for (size_t k = 0; k < devices.size(); ++k) {
+      if (devices[k] == device) return d_addends[k];
+    }
+    return nullptr;
+  }
 };
 } // namespace bz

@@ -128,13 +128,14 @@ void partition_table_slice(typename compact_ops<C>::compact* sums, unsigned w,
   }
 }
 
+// returns false on a short write
 template <class C>
-void write_partition_table(std::FILE* f, unsigned w, const void* projective_generators, u64 n) {
+bool write_partition_table(std::FILE* f, unsigned w, const void* projective_generators, u64 n) {
   using ops = compact_ops<C>;
   using point = typename ops::point; // the ABI's projective element
   const point* g = static_cast<const point*>(projective_generators);
   const u32 w32 = w;
-  std::fwrite(&w32, sizeof(w32), 1, f);
+  if (std::fwrite(&w32, sizeof(w32), 1, f) != 1) return false;
   const u64 windows = (n + w - 1) / w;
   std::vector<typename ops::compact> sums(u64{1} << w);
   std::vector<point> slice(w);
@@ -144,8 +145,11 @@ void write_partition_table(std::FILE* f, unsigned w, const void* projective_gene
       slice[i] = idx < n ? g[idx] : ops::identity();
     }
     partition_table_slice<C>(sums.data(), w, slice.data());
-    std::fwrite(sums.data(), sizeof(typename ops::compact), sums.size(), f);
+    if (std::fwrite(sums.data(), sizeof(typename ops::compact), sums.size(), f) != sums.size()) {
+      return false;
+    }
   }
+  return true;
 }
 
 // the first n generators as compact elements (what the reference's accessor.copy_generators

@@ -22,9 +22,18 @@ const curve_vtable* curve_vtable_for(unsigned curve_id) {
 
 msm_context* msm_context_new() {
   auto* ctx = new msm_context();
-  // development overrides of the sort geometry (plan.h)
-  if (const char* v = std::getenv("BLITZAR_AMD_GROUP_ENTRIES")) ctx->tuning.partition_group_entries = std::strtoul(v, nullptr, 10);
-  if (const char* v = std::getenv("BLITZAR_AMD_MAX_WINDOW_BITS")) ctx->tuning.max_window_bits = std::strtoul(v, nullptr, 10);
+  // development overrides of the sort geometry (plan.h), validated like bzamd_set_tuning: a window
+  // width above 16 would overflow the int16 digit storage, one below 2 gives more windows than
+  // k_horner's 256 lanes can fold
+  if (const char* v = std::getenv("BLITZAR_AMD_GROUP_ENTRIES")) {
+    const unsigned long e = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(e >= 64 && e <= kLocalSortCapacity,
+                      "BLITZAR_AMD_GROUP_ENTRIES must be in [64, 6144]");
+    ctx->tuning.partition_group_entries = static_cast<u32>(e);
+  }
+  if (const char* v = std::getenv("BLITZAR_AMD_MAX_WINDOW_BITS")) {
+    msm_context_set_tuning(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)), 0, 0);
+  }
   return ctx;
 }
 void msm_context_free(msm_context* ctx) { delete ctx; }
@@ -40,8 +49,12 @@ void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_ta
   }
   if (max_workspace_bytes != 0) ctx->tuning.max_workspace_bytes = max_workspace_bytes;
 }
-void msm_context_timing_begin(msm_context* ctx, size_t max_calls) { ctx->timer.begin(max_calls); }
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->timer.begin(max_calls);
+}
 size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
   return ctx->timer.collect(out_ms);
 }
 } // namespace bz

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256)
 
 // commitments[k] = canonical encoding of sum_r partials[r * num_outputs + k]: the fold of the
 // per-rank partial results of a row-sharded MSM (SURVEY 8(e) way 2); one lane per output
-template <class C>
+template <class C, bool Encode = true>
 __global__ void __launch_bounds__(64)
     k_fold_encode(u8* __restrict__ out, const typename C::api_projective* __restrict__ partials,
                   u32 num_partials, u32 num_outputs) {
@@ -30,7 +30,11 @@ __global__ void __launch_bounds__(64)
   for (u32 r = 0; r < num_partials; ++r) {
     acc = C::add(acc, C::point_from_api_projective(partials, static_cast<u64>(r) * num_outputs + k));
   }
-  C::encode(out + static_cast<u64>(k) * C::output_size, acc);
+  if constexpr (Encode) {
+    C::encode(out + static_cast<u64>(k) * C::output_size, acc);
+  } else {
+    C::store_projective(out + static_cast<u64>(k) * C::projective_size, acc);
+  }
 }
 
 // out[i] = (i + 1) * base in the curve's C-ABI generator layout: large synthetic generator sets
@@ -125,6 +129,15 @@ template <class C, class R = C> struct curve_tu {
                        num_outputs);
     BZ_HIP_CHECK(hipGetLastError());
   }
+  static void fold_device(u8* d_out, const void* d_partials, u32 num_partials, u32 num_outputs,
+                          hipStream_t stream) {
+    if (num_outputs == 0) return;
+    hipLaunchKernelGGL((k_fold_encode<C, false>), dim3(ceil_div_u32(num_outputs, 64)), dim3(64), 0,
+                       stream, d_out,
+                       static_cast<const typename C::api_projective*>(d_partials), num_partials,
+                       num_outputs);
+    BZ_HIP_CHECK(hipGetLastError());
+  }
   static void generator_multiples(void* d_out, const void* d_base_api, u64 n, hipStream_t stream) {
     if (n == 0) return;
     hipLaunchKernelGGL((k_generator_multiples<C>), dim3(ceil_div_u32(n, 64)), dim3(64), 0, stream,
@@ -143,6 +156,7 @@ template <class C, class R = C> struct curve_tu {
                                  &curve_tu::msm_host_entry,
                                  &curve_tu::fold_encode_host,
                                  &curve_tu::fold_encode_device,
+                                 &curve_tu::fold_device,
                                  &curve_tu::generator_multiples,
                                  sizeof(typename R::addend),
                                  &curve_tu::msm_resident,

@@ -36,6 +36,9 @@ struct curve_vtable {
   void (*fold_encode_host)(u8* out, const void* partials, u32 num_partials, u32 num_outputs);
   void (*fold_encode_device)(u8* d_out, const void* d_partials, u32 num_partials, u32 num_outputs,
                              hipStream_t stream);
+  // the same sums left as raw projective elements (`projective_size` apart)
+  void (*fold_device)(u8* d_out, const void* d_partials, u32 num_partials, u32 num_outputs,
+                      hipStream_t stream);
   // d_out[i] = (i + 1) * base, C-ABI generator layout (synthetic generator sets)
   void (*generator_multiples)(void* d_out, const void* d_base_api, u64 n, hipStream_t stream);
   // resident generator sets (registered once, reused by many calls): their own addend layout
@@ -50,7 +53,7 @@ struct curve_vtable {
                                       hipStream_t stream);
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
-  void (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);
+  bool (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);
   bool (*read_partition_generators)(std::FILE* f, unsigned& window_width,
                                     std::vector<u8>& projective_out, u64& n);
   // BLITZAR_DUMP_DIR recording (fixed/dump.h): compact generators + the reference's type names

@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "blitzar_amd/csrc/base/device.h"
@@ -73,18 +74,46 @@ struct stage_timer {
   ~stage_timer() { release(); }
 };
 
+// One context per device: the workspace arena, the pinned descriptor ring and the stage timer are
+// shared by every MSM call enqueued on that device.  Calls are asynchronous on a caller stream, so
+// two things keep them from trampling each other's workspace:
+//   * `mu` serialises the host side (arena cursor, staging ring, timer) across caller threads;
+//   * every call records `last_done` on its stream when it has enqueued its last kernel, and a
+//     call arriving on a DIFFERENT stream first makes that stream wait for the event -- calls on
+//     one device therefore execute one after the other whatever streams they come in on (they
+//     could not overlap usefully anyway: k_accumulate fills the machine).
 struct msm_context {
   device_arena arena;
   host_stage_ring descriptors; // pinned copies of the column / task descriptors in flight
   msm_tuning tuning;
   stage_timer timer;
+  std::mutex mu;
+  hipEvent_t last_done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
+  bool kernels_configured = false; // hipFuncSetAttribute applies to the device current at the call
+  ~msm_context() {
+    if (last_done != nullptr) (void)hipEventDestroy(last_done);
+  }
+  // order `stream` behind the previous call on this context (no-op on the same stream)
+  void order_after_previous(hipStream_t stream) {
+    if (has_last && last_stream != stream) BZ_HIP_CHECK(hipStreamWaitEvent(stream, last_done, 0));
+  }
+  void mark_enqueued(hipStream_t stream) {
+    if (last_done == nullptr) {
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&last_done, hipEventDisableTiming));
+    }
+    BZ_HIP_CHECK(hipEventRecord(last_done, stream));
+    last_stream = stream;
+    has_last = true;
+  }
 };
 
-// one-time kernel attributes: the partition kernels keep one counter per bucket group in dynamic
-// LDS (a few KiB normally; up to 128 KiB for columns beyond 2^30 rows, plan.h)
-static void configure_sort_kernels() {
-  static bool done = false;
-  if (done) return;
+// per-device kernel attributes: the partition kernels keep one counter per bucket group in dynamic
+// LDS (a few KiB normally; up to 128 KiB for columns beyond 2^30 rows, plan.h).  Called with the
+// context's mutex held and the context's device current.
+static void configure_sort_kernels(msm_context& ctx) {
+  if (ctx.kernels_configured) return;
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recode_packed),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_hist),
@@ -93,7 +122,7 @@ static void configure_sort_kernels() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  done = true;
+  ctx.kernels_configured = true;
 }
 
 // device workspace of one batch of columns (everything carved from the arena)
@@ -139,7 +168,9 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
                  const std::vector<host_column>& cols, const typename C::addend* d_addends,
                  const void* d_api_generators, hipStream_t stream) {
   if (cols.empty()) return;
-  configure_sort_kernels();
+  std::lock_guard<std::mutex> lock(ctx.mu);
+  configure_sort_kernels(ctx);
+  ctx.order_after_previous(stream);
   msm_tuning tune = ctx.tuning;
   bool any_signed = false;
   for (const auto& c : cols) any_signed = any_signed || c.is_signed;
@@ -196,6 +227,7 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     msm_enqueue_batch<C>(ctx, d_out + first_column[k] * static_cast<size_t>(out_stride), out_stride,
                          projective_out, batches[k], d_addends, d_api_generators, stream);
   }
+  ctx.mark_enqueued(stream);
 }
 
 // device arrays of one batch

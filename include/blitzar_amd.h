@@ -25,6 +25,14 @@ const char* bzamd_version(void);
 int bzamd_device_count(void);
 /* 0 = not initialised, SXT_CPU_BACKEND, SXT_GPU_BACKEND */
 int bzamd_active_backend(void);
+/* HIP devices the GPU backend drives from this process (0 before sxt_init / on the cpu backend).
+ * sxt_init takes every visible device (the current one first), capped by the environment variable
+ * BLITZAR_AMD_NUM_DEVICES; a blocking sxt_* call shards its columns / outputs (or the rows of a
+ * single long column) over them, one host thread per device.  BLITZAR_AMD_FORCE_SHARDS=k makes k
+ * logical devices out of the current physical one (testing the sharded paths on a one-GPU box). */
+int bzamd_num_devices(void);
+/* calls with fewer scalar bytes than this stay on one device (default 1 MiB) */
+void bzamd_set_shard_min_bytes(uint64_t bytes);
 /* number of gfx950 kernel launches issued by this process so far (tests use it to prove that the
  * HIP path, not a host path, produced a result) */
 uint64_t bzamd_kernel_launch_count(void);

@@ -6,10 +6,14 @@ import os
 import re
 import subprocess
 
+import sys
+
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import baseline_workloads as wl  # noqa: E402
 SRC = os.path.join(ROOT, "tools", "multi_commitment", "benchmark.cc")
 EXE = os.path.join(ROOT, "tools", "multi_commitment", "_build", "multi_commitment")
 
@@ -23,18 +27,16 @@ def build():
 
 
 def mt19937_bytes(count, boolean):
-    """std::mt19937{0} through libstdc++'s uniform_int_distribution<uint8_t> (Lemire's method on
-    a 32-bit engine: the top bits of every draw)"""
-    raw = np.random.RandomState(0).randint(0, 2**32, size=count, dtype=np.uint64)
-    return ((raw * (2 if boolean else 256)) >> 32).astype(np.uint8)
+    """std::mt19937{0} through libstdc++'s uniform_int_distribution<uint8_t>"""
+    return wl.mt19937_bytes(count, 0, boolean)
 
 
-@pytest.mark.parametrize("n,commitments,nbytes", [(300, 2, 32), (1000, 3, 1), (257, 1, 0)])
-def test_multi_commitment_cli(oracle, n, commitments, nbytes):
+def run_multi_commitment(oracle, backend, n, commitments, nbytes):
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(SRC):
         build()
-    out = subprocess.run([EXE, "cpu", str(n), "2", str(commitments), str(nbytes), "1"],
+    out = subprocess.run([EXE, backend, str(n), "2", str(commitments), str(nbytes), "1"],
                          capture_output=True, text=True, timeout=300, check=True).stdout
+    assert f"backend : {backend}" in out
     assert "throughput (exponentiations / s) :" in out and "compute duration (s) :" in out
     assert f"num_exponentations : {n * commitments}" in out
     got = [bytes.fromhex(h) for h in re.findall(r"commitment \d+ = 0x([0-9a-f]{64})", out)]
@@ -43,6 +45,19 @@ def test_multi_commitment_cli(oracle, n, commitments, nbytes):
     want = oracle.commit(0, [(table[c], False) for c in range(commitments)],
                          oracle.ristretto_generators(n))
     assert [bytes(w) for w in want] == got
+
+
+@pytest.mark.parametrize("n,commitments,nbytes", [(300, 2, 32), (1000, 3, 1), (257, 1, 0)])
+def test_multi_commitment_cli(oracle, n, commitments, nbytes):
+    run_multi_commitment(oracle, "cpu", n, commitments, nbytes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,commitments,nbytes", [(300, 2, 32), (20000, 3, 1), (257, 1, 0)])
+def test_multi_commitment_cli_gpu(oracle, n, commitments, nbytes):
+    """the same clone with the `gpu` argument: the HIP engine behind the drop-in sxt_* entry points
+    with host buffers, in a process that never loaded torch"""
+    run_multi_commitment(oracle, "gpu", n, commitments, nbytes)
 
 
 #--------------------------------------------------------------------------------------------------
@@ -76,9 +91,9 @@ def reference_generators(oracle, cid, n):
     return np.stack([oracle.random_affine(cid, i + 1, i + 2) for i in range(n)])
 
 
-def run_multi_exp(oracle, curve, cid, n, outputs, nbytes, triangle):
+def run_multi_exp(oracle, curve, cid, n, outputs, nbytes, triangle, backend="cpu"):
     exe = build_multi_exp(triangle)
-    env = dict(os.environ, BLITZAR_BACKEND="cpu")
+    env = dict(os.environ, BLITZAR_BACKEND=backend)
     out = subprocess.run([exe, curve, str(n), "1", str(outputs), str(nbytes), "1"], env=env,
                          capture_output=True, text=True, timeout=600, check=True).stdout
     assert f"running {curve} benchmark..." in out and "compute duration (s): " in out
@@ -113,3 +128,18 @@ def test_multi_exp_pip_cli(oracle, curve, cid):
 @pytest.mark.parametrize("curve,cid,n,outputs", [("curve25519", 0, 40, 6), ("bn254", 2, 5, 9)])
 def test_multi_exp_triangle_cli(oracle, curve, cid, n, outputs):
     run_multi_exp(oracle, curve, cid, n=n, outputs=outputs, nbytes=2, triangle=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,cid", [("curve25519", 0), ("bls12_381", 1), ("bn254", 2),
+                                       ("grumpkin", 3)])
+def test_multi_exp_pip_cli_gpu(oracle, curve, cid):
+    """BLITZAR_BACKEND=gpu: fixed-base handles on the HIP engine (the reference benchmark's gpu
+    mode, benchmark/multi_exp_pip/benchmark.m.cc)"""
+    run_multi_exp(oracle, curve, cid, n=37, outputs=3, nbytes=5, triangle=False, backend="gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,cid,n,outputs", [("curve25519", 0, 40, 6), ("bn254", 2, 5, 9)])
+def test_multi_exp_triangle_cli_gpu(oracle, curve, cid, n, outputs):
+    run_multi_exp(oracle, curve, cid, n=n, outputs=outputs, nbytes=2, triangle=True, backend="gpu")

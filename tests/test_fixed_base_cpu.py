@@ -106,8 +106,7 @@ def test_partition_table_file_interop(cpu_backend, oracle, cid, tmp_path, monkey
     h2.close()
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2, 3])
-def test_dump_dir_record_and_replay(cpu_backend, oracle, cid, tmp_path, monkeypatch):
+def dump_record_and_replay(api, backend_id, oracle, cid, tmp_path, monkeypatch):
     """BLITZAR_DUMP_DIR writes the reference's recording layout
     (multiexponentiation_serialization.h:70-103, gpu_backend.cc:286-301,317-332); the recording
     replays to the same result, and its generators.bin is the reference's compact form"""
@@ -118,7 +117,7 @@ def test_dump_dir_record_and_replay(cpu_backend, oracle, cid, tmp_path, monkeypa
     from oracle import fixed_base
     proj = GOLDEN[f"curve{cid}_fixed_projective_generators"]
     monkeypatch.setenv("BLITZAR_DUMP_DIR", str(tmp_path))
-    h = cpu_backend.MultiexpHandle(cid, proj)
+    h = api.MultiexpHandle(cid, proj)
     n = proj.shape[0]
     h.packed_multiexponentiation(GOLDEN["fixed_bit_table"], n, GOLDEN[f"curve{cid}_fixed_scalars"])
     bt, lengths = [4, 12, 1], [0, 5, n]
@@ -140,4 +139,24 @@ def test_dump_dir_record_and_replay(cpu_backend, oracle, cid, tmp_path, monkeypa
     assert np.array_equal(got, want)
     assert np.fromfile(packed / "window_width.bin", np.uint64).tolist() == [16]
     for d in dirs:
-        assert replay_dump.replay(str(tmp_path / d), cpu_backend.SXT_CPU_BACKEND)[2]
+        assert replay_dump.replay(str(tmp_path / d), backend_id)[2]
+    # the recorded result itself is the right group element (not only self-consistent)
+    res = np.fromfile(packed / "result.bin", np.uint8).reshape(len(GOLDEN["fixed_bit_table"]), -1)
+    assert np.array_equal(canon(oracle, cid, res), GOLDEN[f"curve{cid}_fixed_canonical"])
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_dump_dir_record_and_replay(cpu_backend, oracle, cid, tmp_path, monkeypatch):
+    dump_record_and_replay(cpu_backend, cpu_backend.SXT_CPU_BACKEND, oracle, cid, tmp_path,
+                           monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_dump_dir_record_and_replay_gpu(gpu_backend, oracle, cid, tmp_path, monkeypatch):
+    """the reference records dumps on its GPU backend only (gpu_backend.cc:286-301,317-332):
+    record through the HIP engine, replay through the HIP engine"""
+    before = gpu_backend.load().bzamd_kernel_launch_count()
+    dump_record_and_replay(gpu_backend, gpu_backend.SXT_GPU_BACKEND, oracle, cid, tmp_path,
+                           monkeypatch)
+    assert gpu_backend.load().bzamd_kernel_launch_count() > before

@@ -1,0 +1,157 @@
+"""Multi-device execution INSIDE the C ABI (one process drives every device, like the reference's
+gpu backend: sxt/execution/device/for_each.cc:56-82, gpu_backend.cc:150-193).
+
+There is one GPU per box here, so the sharded code paths are forced the way the reference's own
+tests force chunking with split_options (pippenger2/multiexponentiation.t.cc:150-180):
+BLITZAR_AMD_FORCE_SHARDS=k makes k logical devices -- host threads on the cpu backend (runs
+anywhere), k stream/context/arena sets on the one physical GPU under -m gpu.  Every sharded result
+must equal the reference oracle's, whatever the split: columns over devices, rows of a single
+long column over devices (projective partials + fold), outputs of a fixed-base call over devices.
+Each case runs in a child process: the shard count is read once at sxt_init.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+backend = {backend}
+if backend == 2:
+    import torch  # the HIP runtime torch ships must be the one the library binds to
+from blitzar_amd import api
+from tests import util
+lib = api.load()
+assert api.init(backend, 64) == 0
+assert lib.bzamd_num_devices() == {shards}
+lib.bzamd_set_shard_min_bytes(0)
+rng = np.random.default_rng({seed})
+out = {{}}
+launches = lib.bzamd_kernel_launch_count()
+for cid in {curves}:
+    n = {n}
+    gens = util.generators_for(cid, n)
+    g = util.api_generators(cid, gens)
+    many = util.mixed_columns(rng, n)[:11]                       # >= shards columns: column split
+    few = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False),
+           (rng.integers(0, 256, (n - 3, 8), dtype=np.uint8), True)]  # < shards: row split
+    out[f"many{{cid}}"] = api.compute_pedersen_commitments(cid, many, generators=g).tolist()
+    out[f"few{{cid}}"] = api.compute_pedersen_commitments(cid, few, generators=g).tolist()
+    if cid == 0:
+        out["builtin_few"] = api.compute_pedersen_commitments(0, few, offset_generators=7).tolist()
+        out["builtin_many"] = api.compute_pedersen_commitments(0, many, offset_generators=50).tolist()
+    proj = gens if cid == 0 else util.ref_oracle.affine_to_projective(cid, gens)
+    h = api.MultiexpHandle(cid, proj)
+    bt = [8, 32, 256, 5, 1, 64, 13]
+    s = rng.integers(0, 256, (n, (sum(bt) + 7) // 8), dtype=np.uint8)
+    out[f"packed{{cid}}"] = h.packed_multiexponentiation(bt, n, s).tolist()
+    lengths = [0, 5, 5, 9, n // 2, n - 1, n]
+    out[f"vlen{{cid}}"] = h.vlen_multiexponentiation(bt, lengths, s).tolist()
+    h.close()
+out["launches"] = int(lib.bzamd_kernel_launch_count() - launches)
+print("RESULT" + json.dumps(out))
+"""
+
+
+def run_child(backend, shards, curves, n, seed):
+    env = dict(os.environ, BLITZAR_AMD_FORCE_SHARDS=str(shards))
+    env.pop("BLITZAR_BACKEND", None)
+    code = CHILD.format(root=ROOT, backend=backend, shards=shards, curves=curves, n=n, seed=seed)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = next(ln for ln in r.stdout.splitlines() if ln.startswith("RESULT"))
+    return json.loads(line[len("RESULT"):])
+
+
+def expected(oracle, curves, n, seed):
+    from oracle import fixed_base
+    rng = np.random.default_rng(seed)
+    want = {}
+    for cid in curves:
+        gens = util.generators_for(cid, n)
+        many = util.mixed_columns(rng, n)[:11]
+        few = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False),
+               (rng.integers(0, 256, (n - 3, 8), dtype=np.uint8), True)]
+        want[f"many{cid}"] = oracle.commit(cid, many, gens)
+        want[f"few{cid}"] = oracle.commit(cid, few, gens)
+        if cid == 0:
+            want["builtin_few"] = oracle.commit(0, few, oracle.ristretto_generators(n, 7))
+            want["builtin_many"] = oracle.commit(0, many, oracle.ristretto_generators(n, 50))
+        bt = [8, 32, 256, 5, 1, 64, 13]
+        s = rng.integers(0, 256, (n, (sum(bt) + 7) // 8), dtype=np.uint8)
+        want[f"packed{cid}"] = oracle.commit(cid, fixed_base.unpack_columns(bt, n, s), gens)
+        lengths = [0, 5, 5, 9, n // 2, n - 1, n]
+        want[f"vlen{cid}"] = oracle.commit(cid, fixed_base.unpack_columns(bt, n, s, lengths), gens)
+    return want
+
+
+def check(oracle, got, want, curves):
+    for key, w in want.items():
+        g = np.array(got[key], dtype=np.uint8)
+        if key.startswith(("packed", "vlen")):
+            cid = int(key[-1])
+            words = g.view(np.uint64).reshape(g.shape[0], -1)
+            g = np.stack([np.ascontiguousarray(oracle.canonical(cid, p)).view(np.uint8).reshape(-1)
+                          for p in words])[:, :w.shape[1]]
+        assert np.array_equal(g, w), f"{key} differs"
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_forced_shards_host_backend(oracle, shards):
+    curves, n, seed = [0, 2], 4000, 600 + shards
+    got = run_child(1, shards, curves, n, seed)
+    check(oracle, got, expected(oracle, curves, n, seed), curves)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards,curves", [(2, [0, 1]), (3, [2]), (8, [0, 3])])
+def test_forced_shards_gpu_backend(oracle, shards, curves):
+    """k logical devices on the one physical GPU: per-device threads, streams, contexts and arenas,
+    direct D2H of column shards, hipMemcpyPeerAsync of row-split partials into device 0 and the
+    fold-and-encode kernel, strided uploads of fixed-base output ranges"""
+    n, seed = 6000, 700 + shards
+    got = run_child(2, shards, curves, n, seed)
+    assert got["launches"] > 10 * shards
+    check(oracle, got, expected(oracle, curves, n, seed), curves)
+
+
+def test_split_by_weight_is_a_partition():
+    """the split helper through its observable effect: any shard count gives the single-shard
+    answer (ragged: more shards than columns, empty and zero-length columns)"""
+    from blitzar_amd import api
+    rng = np.random.default_rng(9)
+    n = 1500
+    cols = [(rng.integers(0, 256, (n, 4), dtype=np.uint8), False),
+            (np.zeros((0, 8), np.uint8), False),
+            (rng.integers(0, 256, (n // 3, 32), dtype=np.uint8), False)]
+    code = (
+        "import sys, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from blitzar_amd import api\n"
+        "assert api.init(api.SXT_CPU_BACKEND, 0) == 0\n"
+        "api.load().bzamd_set_shard_min_bytes(0)\n"
+        "rng = np.random.default_rng(9)\n"
+        f"n = {n}\n"
+        "cols = [(rng.integers(0, 256, (n, 4), dtype=np.uint8), False),\n"
+        "        (np.zeros((0, 8), np.uint8), False),\n"
+        "        (rng.integers(0, 256, (n // 3, 32), dtype=np.uint8), False)]\n"
+        "print('RESULT' + json.dumps(api.compute_pedersen_commitments(0, cols).tolist()))\n")
+    outs = []
+    for shards in (1, 2, 3, 5):
+        env = dict(os.environ, BLITZAR_AMD_FORCE_SHARDS=str(shards))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(next(ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")))
+    assert len(set(outs)) == 1
+    _ = (api, cols)

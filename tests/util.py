@@ -5,9 +5,14 @@ from oracle import ref_oracle
 
 
 def mt_bytes(seed, n):
-    """byte stream of std::mt19937{seed} through uniform_int_distribution<uint8_t> is not
-    reproducible from numpy; tests only need *seeded* bytes, bench.py documents its own stream."""
-    return np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)
+    """byte stream of std::mt19937{seed} through libstdc++'s uniform_int_distribution<uint8_t>
+    (the reference benchmarks' input recipe); see tools/baseline_workloads.py"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import baseline_workloads
+    return baseline_workloads.mt19937_bytes(n, seed)
 
 
 def weierstrass_generators(curve_id, n, distinct_seeds=64):
