@@ -42,8 +42,6 @@ void init_host_generators(api_state& st, u64 n) {
   if (n == 0) return;
   if (st.backend == SXT_GPU_BACKEND) {
     // derive on the device (reference K15)
-    BZ_RELEASE_ASSERT(curve25519_vtable().addend_size == sizeof(ed29_cached_packed),
-                      "built-in generator derivation and MSM engine disagree on the addend layout");
     for (auto& dsp : st.devices) {
       device_state& ds = *dsp;
       ds.activate();
@@ -219,7 +217,8 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   const size_t gen_bytes = gens.source == generator_source::host_api
                                ? device_arena::padded(vt.api_generator_size * longest + 32) +
                                      device_arena::padded(vt.addend_size * (longest + 1))
-                               : device_arena::padded(vt.addend_size * (longest + 1));
+                               : device_arena::padded(sizeof(ed_point) * (longest + 1)) +
+                                     device_arena::padded(vt.addend_size * (longest + 1));
   const size_t out_bytes = device_arena::padded(static_cast<size_t>(out_stride) * cols.size());
   ds.io.reset(total_bytes + gen_bytes + out_bytes + 1024, ds.stream);
   if (ds.copy_stream == nullptr) {
@@ -257,10 +256,12 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   } else {
     // beyond the init-time cache: derived on the fly for any offset, like the reference
     // (precomputed_generators.cc:56-91)
-    ed29_cached_packed* d = ds.io.take<ed29_cached_packed>(longest + 1);
-    builtin_addends_enqueue(d, gens.offset, longest, ds.stream);
-    g_kernel_launches += 1;
-    d_addends = d;
+    ed_point* d_raw = ds.io.take<ed_point>(longest + 1);
+    void* prepared = ds.io.take<u8>(vt.addend_size * (longest + 1));
+    builtin_generators_enqueue(d_raw, gens.offset, longest, ds.stream);
+    vt.prepare_addends(prepared, d_raw, longest, ds.stream);
+    g_kernel_launches += 2;
+    d_addends = prepared;
   }
   u8* d_out = ds.io.take<u8>(static_cast<size_t>(out_stride) * cols.size());
 
@@ -930,6 +931,11 @@ int bzamd_num_devices(void) {
 }
 
 void bzamd_set_shard_min_bytes(uint64_t bytes) { g_shard_min_bytes.store(bytes); }
+
+int bzamd_accumulate_form(void) {
+  // curve25519 caller generators are normalised to Z = 1 on every call (batched inversion)
+  return curve25519_vtable().addend_size == sizeof(ed29_niels) ? 1 : 0;
+}
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
 

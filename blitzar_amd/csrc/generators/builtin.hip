@@ -8,11 +8,6 @@ __global__ void __launch_bounds__(64) k_base_elements(ed_point* __restrict__ out
   out[i] = ed::base_element(first + i);
 }
 
-__global__ void __launch_bounds__(64) k_base_addends(ed29_cached_packed* __restrict__ out, u64 first, u64 n) {
-  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[i] = ed29::pack(ed29::cached_from_ed(ed::base_element(first + i)));
-}
 } // namespace
 
 void builtin_generators_enqueue(ed_point* d_out, u64 first, u64 n, hipStream_t stream) {
@@ -22,10 +17,4 @@ void builtin_generators_enqueue(ed_point* d_out, u64 first, u64 n, hipStream_t s
   BZ_HIP_CHECK(hipGetLastError());
 }
 
-void builtin_addends_enqueue(ed29_cached_packed* d_out, u64 first, u64 n, hipStream_t stream) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(k_base_addends, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(64), 0,
-                     stream, d_out, first, n);
-  BZ_HIP_CHECK(hipGetLastError());
-}
 } // namespace bz

@@ -45,6 +45,7 @@ struct ed25519_msm {
   // (measured on MI355X at config 2: 2 / 3 / 4 waves per SIMD -> 0.862 / 0.860 / 1.13 ms, the last
   // one spills: the kernel is issue-bound, not latency-bound)
   static constexpr int accumulate_waves_per_simd = 3;
+  static constexpr bool has_batched_prepare = false;
 
   BZ_HD static point identity() { return ed29::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return ed29::add(a, b); }
@@ -140,6 +141,35 @@ struct ed25519_niels_msm : ed25519_msm {
   BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {
     return make_addend(projective, i);
   }
+  // batched normalisation (k_prepare_addends_batched): the inversions of a workgroup's generators
+  // share one exponentiation
+  static constexpr bool has_batched_prepare = true;
+  using batch_fe = fe29;
+  BZ_HD static fe29 batch_one() { return f29::one(); }
+  BZ_HD static fe29 batch_mul(const fe29& a, const fe29& b) { return f29::mul(a, b); }
+  BZ_HD static fe29 batch_load_z(const void* api_generators, u64 i) {
+    return f29::from_fe51(static_cast<const ed_point*>(api_generators)[i].Z);
+  }
+  BZ_HD static addend batch_make_addend(const void* api_generators, u64 i, const fe29& zinv) {
+    const ed_point& g = static_cast<const ed_point*>(api_generators)[i];
+    const fe29 x = f29::mul(f29::from_fe51(g.X), zinv);
+    const fe29 y = f29::mul(f29::from_fe51(g.Y), zinv);
+    ed29_niels n;
+    n.YpX = f29::weak_reduce(f29::add(y, x));
+    n.YmX = f29::weak_reduce(f29::sub(y, x));
+    n.T2d = f29::mul(f29::mul(x, y), f29::const_2d());
+    for (int k = 0; k < 5; ++k) n.pad[k] = 0;
+    return n;
+  }
+#if defined(__HIPCC__)
+  // 1 / z by the 64 lanes of one wavefront (every lane passes the same z and gets the result):
+  // z^(p - 2) = (z^(2^252 - 3))^8 * z^3, the long exponentiation row-parallel (curve/ed16_wave.h)
+  __device__ static fe29 batch_wave_invert(const fe29& z) {
+    const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
+    const fe29 t = ed16w::pow22523(c, z);
+    return f29::mul(f29::sqn(t, 3), f29::mul(f29::sq(z), z));
+  }
+#endif
 };
 
 // Weierstrass curves: the kernels compute on the unsaturated-limb Montgomery representation
@@ -157,6 +187,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr size_t api_generator_size = sizeof(api_affine);
   static constexpr size_t projective_size = sizeof(api_projective);
   static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
+  static constexpr bool has_batched_prepare = false;
   static constexpr bool has_wave_encode = false;
   static constexpr bool has_wave_add_multiple = false;
   // k_horner's dependent chain on one wavefront: doublings split over the lanes of each DPP quad

@@ -55,8 +55,10 @@ __global__ void __launch_bounds__(64)
   C::store_api_generator(out + i * C::api_generator_size, acc);
 }
 
-// R = the trait used against resident generator sets (C itself, except curve25519's Z = 1 form)
-template <class C, class R = C> struct curve_tu {
+// R = the trait used against resident generator sets, H = the trait of the host backend (both C
+// itself, except curve25519: the host backend keeps the projective cached addends -- one inversion
+// per generator is only worth it where the inversions are batched on the device)
+template <class C, class R = C, class H = C> struct curve_tu {
   static void msm_resident(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                            const std::vector<host_column>& cols, const void* d_addends,
                            hipStream_t stream) {
@@ -65,9 +67,8 @@ template <class C, class R = C> struct curve_tu {
   }
   static void prepare_resident(void* d_addends, const void* d_api_generators, u64 n,
                                hipStream_t stream) {
-    if (n == 0) return;
-    hipLaunchKernelGGL((k_prepare_addends<R>), dim3(ceil_div_u32(n, 256)), dim3(256), 0, stream,
-                       static_cast<typename R::addend*>(d_addends), d_api_generators, n);
+    launch_prepare_addends<R>(static_cast<typename R::addend*>(d_addends), d_api_generators, n,
+                              stream);
     BZ_HIP_CHECK(hipGetLastError());
   }
   static void prepare_resident_projective(void* d_addends, const void* d_projective, u64 n,
@@ -86,9 +87,8 @@ template <class C, class R = C> struct curve_tu {
   }
   static void prepare_addends(void* d_addends, const void* d_api_generators, u64 n,
                               hipStream_t stream) {
-    if (n == 0) return;
-    hipLaunchKernelGGL((k_prepare_addends<C>), dim3(ceil_div_u32(n, 256)), dim3(256), 0, stream,
-                       static_cast<typename C::addend*>(d_addends), d_api_generators, n);
+    launch_prepare_addends<C>(static_cast<typename C::addend*>(d_addends), d_api_generators, n,
+                              stream);
     BZ_HIP_CHECK(hipGetLastError());
   }
   static void prepare_addends_projective(void* d_addends, const void* d_projective, u64 n,
@@ -102,13 +102,13 @@ template <class C, class R = C> struct curve_tu {
   static void msm_host_entry(u8* out, u32 out_stride, bool projective_out,
                              const std::vector<host_column>& cols, const void* generators,
                              bool generators_projective, u64 num_generators) {
-    std::vector<typename C::addend> addends(num_generators);
+    std::vector<typename H::addend> addends(num_generators);
     for (u64 i = 0; i < num_generators; ++i) {
       addends[i] = generators_projective
-                       ? C::addend_from_api_projective(generators, i)
-                       : C::make_addend(generators, i);
+                       ? H::addend_from_api_projective(generators, i)
+                       : H::make_addend(generators, i);
     }
-    msm_host<C>(out, out_stride, projective_out, cols, addends.data());
+    msm_host<H>(out, out_stride, projective_out, cols, addends.data());
   }
   static void fold_encode_host(u8* out, const void* partials, u32 num_partials, u32 num_outputs) {
     for (u32 k = 0; k < num_outputs; ++k) {
@@ -162,10 +162,10 @@ template <class C, class R = C> struct curve_tu {
                                  &curve_tu::msm_resident,
                                  &curve_tu::prepare_resident,
                                  &curve_tu::prepare_resident_projective,
-                                 sizeof(typename compact_ops<C>::compact),
-                                 &write_partition_table<C>,
-                                 &read_partition_generators<C>,
-                                 &write_compact_generators<C>,
+                                 sizeof(typename compact_ops<H>::compact),
+                                 &write_partition_table<H>,
+                                 &read_partition_generators<H>,
+                                 &write_compact_generators<H>,
                                  C::reference_element_name,
                                  C::reference_compact_name};
     return vt;

@@ -92,8 +92,25 @@ struct msm_context {
   hipStream_t last_stream = nullptr;
   bool has_last = false;
   bool kernels_configured = false; // hipFuncSetAttribute applies to the device current at the call
+  // side stream of a call: the conversion of caller generators (k_prepare_addends*: latency-bound
+  // when it shares inversions) runs beside the recoding and sorting of the scalars, which do not
+  // depend on it; joined before k_accumulate
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool overlap_prepare = false; // BLITZAR_AMD_OVERLAP_PREPARE=1 (no gain for the HBM-bound per-point conversion)
   ~msm_context() {
     if (last_done != nullptr) (void)hipEventDestroy(last_done);
+    if (fork != nullptr) (void)hipEventDestroy(fork);
+    if (join != nullptr) (void)hipEventDestroy(join);
+    if (side != nullptr) (void)hipStreamDestroy(side);
+  }
+  hipStream_t side_stream() {
+    if (side == nullptr) {
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    }
+    return side;
   }
   // order `stream` behind the previous call on this context (no-op on the same stream)
   void order_after_previous(hipStream_t stream) {
@@ -150,7 +167,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   return need;
 }
 
-inline u32 partial_stride_of(const msm_plan& plan) {
+static inline u32 partial_stride_of(const msm_plan& plan) {
   return plan.max_task_buckets == 0 ? 1 : ceil_div_u32(plan.max_task_buckets, kReduceBlockBuckets);
 }
 
@@ -298,12 +315,20 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     return;
   }
   const bool timing = ctx.timer.recording();
+  bool join_prepare = false;
   if (d_addends == nullptr) {
     addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
-    ctx.timer.timed(timing, 0, stream, [&] {
-      hipLaunchKernelGGL((k_prepare_addends<C>), dim3(ceil_div_u32(plan.max_rows, 256)), dim3(256),
-                         0, stream, prepared, d_api_generators, plan.max_rows);
+    hipStream_t where = stream;
+    if (ctx.overlap_prepare) {
+      where = ctx.side_stream();
+      BZ_HIP_CHECK(hipEventRecord(ctx.fork, stream));
+      BZ_HIP_CHECK(hipStreamWaitEvent(where, ctx.fork, 0));
+      join_prepare = true;
+    }
+    ctx.timer.timed(timing, 0, where, [&] {
+      launch_prepare_addends<C>(prepared, d_api_generators, plan.max_rows, where);
     });
+    if (join_prepare) BZ_HIP_CHECK(hipEventRecord(ctx.join, where));
     d_addends = prepared;
   }
   b.addends = d_addends;
@@ -377,6 +402,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
                        b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
   });
+  if (join_prepare) BZ_HIP_CHECK(hipStreamWaitEvent(stream, ctx.join, 0));
   ctx.timer.timed(timing, 3, stream, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
                        stream, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,

@@ -28,6 +28,8 @@
 // No MFMA anywhere: the arithmetic is carry-propagating multi-limb integer math.
 #pragma once
 
+#include <utility>
+
 #include "blitzar_amd/csrc/msm/curve_traits.h"
 #include "blitzar_amd/csrc/msm/plan.h"
 #include "blitzar_amd/csrc/msm/recode.h"
@@ -54,6 +56,97 @@ __global__ void __launch_bounds__(256)
   const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   addends[i] = C::make_addend(api_generators, i);
+}
+
+// curve25519: caller generators arrive as projective element_p3 (any Z).  Normalising them to
+// Z = 1 lets k_accumulate run the 7-product addition on 128-byte raw-limb rows (ed29_niels: nothing
+// to unpack) instead of the 8-product one -- 16 additions per generator saved one product each --
+// but costs an inversion per generator unless the inversions are shared: a workgroup takes
+// 256 x kBatchPreparePoints generators, every lane multiplies its Z's up (Montgomery's trick), the
+// 256 lane products meet in a binary product tree in LDS, the root is inverted ONCE by the first
+// wavefront with the element spread over its lanes (ed16w::pow22523: ~250 row-parallel squarings,
+// ~50 us -- every workgroup of the launch is in this phase at the same time, so it is paid once),
+// and the inverse travels back down the tree and through the lanes' prefix products: 3 products per
+// generator for the inversion instead of ~265, then x = X / Z, y = Y / Z, 2d x y.
+// (C::batch_* hooks: curve_traits.h.  T is recomputed from x and y; a caller's T is only ever
+// XY / Z, cbindings/blitzar_api.h:66-71.)
+constexpr u32 kBatchPrepareThreads = 256;
+constexpr u32 kBatchPreparePoints = 4;
+// f(0), f(1), ..., f(N - 1) with compile-time indices (per-lane arrays stay in registers)
+template <u32 N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  [&]<u32... J>(std::integer_sequence<u32, J...>) {
+    (f(std::integral_constant<u32, J>{}), ...);
+  }(std::make_integer_sequence<u32, N>{});
+}
+#ifndef BZ_BATCH_PREPARE_WAVES
+#define BZ_BATCH_PREPARE_WAVES 1
+#endif
+template <class C>
+__global__ void __launch_bounds__(kBatchPrepareThreads, BZ_BATCH_PREPARE_WAVES)
+    k_prepare_addends_batched(typename C::addend* __restrict__ addends,
+                              const void* __restrict__ api_generators, u64 n) {
+  using fe = typename C::batch_fe;
+  __shared__ fe tree[2 * kBatchPrepareThreads]; // heap order: root 1, leaves 256 + lane
+  const u32 tid = threadIdx.x;
+  const u64 base = static_cast<u64>(blockIdx.x) * kBatchPrepareThreads * kBatchPreparePoints;
+  fe z[kBatchPreparePoints], prefix[kBatchPreparePoints];
+  static_for<kBatchPreparePoints>([&](auto jc) {
+    constexpr u32 j = decltype(jc)::value;
+    const u64 i = base + static_cast<u64>(j) * kBatchPrepareThreads + tid;
+    z[j] = i < n ? C::batch_load_z(api_generators, i) : C::batch_one();
+    if constexpr (j == 0) {
+      prefix[0] = z[0];
+    } else {
+      prefix[j] = C::batch_mul(prefix[j - 1], z[j]);
+    }
+  });
+  tree[kBatchPrepareThreads + tid] = prefix[kBatchPreparePoints - 1];
+  __syncthreads();
+  for (u32 s = kBatchPrepareThreads / 2; s >= 1; s >>= 1) {
+    if (tid < s) tree[s + tid] = C::batch_mul(tree[2 * (s + tid)], tree[2 * (s + tid) + 1]);
+    __syncthreads();
+  }
+  if (tid < 64) {
+    const fe inv = C::batch_wave_invert(tree[1]); // all 64 lanes cooperate, all get the result
+    if (tid == 0) tree[1] = inv;
+  }
+  __syncthreads();
+  // node i holds the inverse of its subtree's product; its children get inv * (the sibling)
+  for (u32 s = 1; s < kBatchPrepareThreads; s <<= 1) {
+    if (tid < s) {
+      const u32 i = s + tid;
+      const fe inv = tree[i], left = tree[2 * i], right = tree[2 * i + 1];
+      tree[2 * i] = C::batch_mul(inv, right);
+      tree[2 * i + 1] = C::batch_mul(inv, left);
+    }
+    __syncthreads();
+  }
+  fe inv = tree[kBatchPrepareThreads + tid];
+  static_for<kBatchPreparePoints>([&](auto jc) {
+    constexpr u32 j = kBatchPreparePoints - 1 - decltype(jc)::value;
+    fe zinv = inv;
+    if constexpr (j != 0) {
+      zinv = C::batch_mul(inv, prefix[j - 1]);
+      inv = C::batch_mul(inv, z[j]);
+    }
+    const u64 i = base + static_cast<u64>(j) * kBatchPrepareThreads + tid;
+    if (i < n) addends[i] = C::batch_make_addend(api_generators, i, zinv);
+  });
+}
+
+// C-ABI generators -> addends, by the curve's cheapest route
+template <class C>
+void launch_prepare_addends(typename C::addend* d_addends, const void* d_api_generators, u64 n,
+                            hipStream_t stream) {
+  if (n == 0) return;
+  if constexpr (C::has_batched_prepare) {
+    const u64 per_block = static_cast<u64>(kBatchPrepareThreads) * kBatchPreparePoints;
+    hipLaunchKernelGGL((k_prepare_addends_batched<C>), dim3(ceil_div_u32(n, per_block)),
+                       dim3(kBatchPrepareThreads), 0, stream, d_addends, d_api_generators, n);
+  } else {
+    hipLaunchKernelGGL((k_prepare_addends<C>), dim3(ceil_div_u32(n, 256)), dim3(256), 0, stream,
+                       d_addends, d_api_generators, n);
+  }
 }
 
 //--------------------------------------------------------------------------------------------------
@@ -923,7 +1016,6 @@ __global__ void __launch_bounds__(kReduceThreads)
              const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
              const task_desc* __restrict__ tasks) {
   using point = typename C::point;
-  static_assert(kReduceSegment == 8);
   __shared__ point tree[kReduceThreads];
   const task_desc task = tasks[blockIdx.y];
   const u32 nb = task.num_buckets;
@@ -1016,8 +1108,8 @@ __global__ void __launch_bounds__(kReduceThreads)
       if (tid + d < kReduceThreads) x = C::add(x, tree[tid + d]);
       __syncthreads();
     }
-    // v_t = r_t + 8 suffix_t (t >= 1), folded by the tree
-    if (tid != 0) r = C::add(r, C::dbl_n(x, 3));
+    // v_t = r_t + kReduceSegment * suffix_t (t >= 1), folded by the tree
+    if (tid != 0) r = C::add(r, C::dbl_n(x, static_cast<int>(kReduceSegmentLog2)));
     tree[tid] = r;
     __syncthreads();
     for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {

@@ -36,7 +36,11 @@ constexpr u32 kMaxGroupsLog2 = 10;        // pass 1 writes one stream per group:
 
 // buckets a reduce block covers (threads per block x buckets per thread), shared with kernels.h
 constexpr u32 kReduceThreads = 256;
-constexpr u32 kReduceSegment = 8;
+#ifndef BZ_REDUCE_SEGMENT_LOG2
+#define BZ_REDUCE_SEGMENT_LOG2 3
+#endif
+constexpr u32 kReduceSegmentLog2 = BZ_REDUCE_SEGMENT_LOG2; // buckets per k_reduce lane = 2^this
+constexpr u32 kReduceSegment = 1u << kReduceSegmentLog2;
 constexpr u32 kReduceBlockBuckets = kReduceThreads * kReduceSegment;
 
 // device-visible task descriptor

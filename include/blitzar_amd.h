@@ -33,6 +33,9 @@ int bzamd_active_backend(void);
 int bzamd_num_devices(void);
 /* calls with fewer scalar bytes than this stay on one device (default 1 MiB) */
 void bzamd_set_shard_min_bytes(uint64_t bytes);
+/* addition formula k_accumulate runs for curve25519 caller generators: 1 = Z = 1 addends (7 field
+ * products, generators normalised per call by a batched inversion), 0 = projective (8 products) */
+int bzamd_accumulate_form(void);
 /* number of gfx950 kernel launches issued by this process so far (tests use it to prove that the
  * HIP path, not a host path, produced a result) */
 uint64_t bzamd_kernel_launch_count(void);

@@ -395,3 +395,48 @@ def test_sw29_group_law_matches_reference(oracle, cid):
     xy = np.stack([gens[i, :16 * nl].view(np.uint64) for i in order])
     got = hooks.sw29_chain(cid, ident, xy, signs)
     assert np.array_equal(canon(got), canon(acc))
+
+
+def test_batched_inversion_tree_model():
+    """k_prepare_addends_batched (msm/kernels.h) shares one inversion among the 1024 generators of
+    a workgroup: lane prefix products, a binary product tree in heap order, the root inverted once,
+    the inverse pushed back down (children get inv * sibling) and through the lanes' prefixes.
+    The index logic, restated over integers mod p with the kernel's exact loop structure."""
+    import random
+    p = 2**255 - 19
+    T, K = 256, 4
+    rng = random.Random(5)
+    for n in (1, 5, 255, 256, 1000, 1024):
+        zs = [rng.randrange(1, p) for _ in range(n)]
+        z = [[zs[j * T + t] if j * T + t < n else 1 for j in range(K)] for t in range(T)]
+        prefix = [[0] * K for _ in range(T)]
+        tree = [0] * (2 * T)
+        for t in range(T):
+            for j in range(K):
+                prefix[t][j] = z[t][0] if j == 0 else prefix[t][j - 1] * z[t][j] % p
+            tree[T + t] = prefix[t][K - 1]
+        s = T // 2
+        while s >= 1:
+            for t in range(s):
+                tree[s + t] = tree[2 * (s + t)] * tree[2 * (s + t) + 1] % p
+            s >>= 1
+        tree[1] = pow(tree[1], p - 2, p)
+        s = 1
+        while s < T:
+            new = {}
+            for t in range(s):
+                i = s + t
+                new[2 * i] = tree[i] * tree[2 * i + 1] % p
+                new[2 * i + 1] = tree[i] * tree[2 * i] % p
+            for k, v in new.items():
+                tree[k] = v
+            s <<= 1
+        for t in range(T):
+            inv = tree[T + t]
+            for j in range(K - 1, -1, -1):
+                zinv = inv if j == 0 else inv * prefix[t][j - 1] % p
+                if j != 0:
+                    inv = inv * z[t][j] % p
+                i = j * T + t
+                if i < n:
+                    assert zinv * zs[i] % p == 1

@@ -18,17 +18,25 @@
     }                                                                                              \
   } while (0)
 
-constexpr int kIters = 4096;
+constexpr int kIters = 16384;
 constexpr int kUnroll = 8; // independent chains per lane
 
 // Each kernel runs kIters x kUnroll instances of one instruction per lane on independent chains.
+// Thread 0 of every block also records the s_memtime ticks (= shader cycles,
+// MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units") its wave spent in the loop: the host
+// divides wall time by them to get the EFFECTIVE shader clock under this load (the part clocks to
+// its power budget, well below the 2.4 GHz hipDeviceProp reports), and reports cycles per
+// wave-instruction in real shader cycles next to the nominal-clock figure.
 #define DEFINE_KERNEL(name, decl, body, sink)                                                      \
-  __global__ void __launch_bounds__(256) name(uint64_t* out, uint32_t seed) {                     \
+  __global__ void __launch_bounds__(256) name(uint64_t* out, uint64_t* ticks, uint32_t seed) {    \
     decl;                                                                                          \
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();                                              \
     for (int it = 0; it < kIters; ++it) {                                                          \
       body                                                                                         \
     }                                                                                              \
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();                                              \
     out[blockIdx.x * 256 + threadIdx.x] = sink;                                                    \
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;                                             \
   }
 
 #define U64X8                                                                                      \
@@ -110,18 +118,22 @@ DEFINE_KERNEL(k_fma_f32, F32X8, REP8(FMA32),
               (uint64_t)__float_as_uint(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7))
 
 // dependent single chain of mad_u64_u32 (latency)
-__global__ void __launch_bounds__(256) k_mad_u64_u32_dep(uint64_t* out, uint32_t seed) {
+__global__ void __launch_bounds__(256) k_mad_u64_u32_dep(uint64_t* out, uint64_t* ticks,
+                                                         uint32_t seed) {
   uint64_t a0 = seed + threadIdx.x;
   uint32_t x = seed * 2654435761u + threadIdx.x, y = x ^ 0x9e3779b9u;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < kIters; ++it) {
     MAD64(a0) MAD64(a0) MAD64(a0) MAD64(a0) MAD64(a0) MAD64(a0) MAD64(a0) MAD64(a0)
   }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * 256 + threadIdx.x] = a0;
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
 struct bench {
   const char* name;
-  void (*fn)(uint64_t*, uint32_t);
+  void (*fn)(uint64_t*, uint64_t*, uint32_t);
 };
 
 int main() {
@@ -131,8 +143,11 @@ int main() {
   const double clk_ghz = prop.clockRate * 1e-6;
   std::printf("device %s  CUs %d  clock %.2f GHz\n", prop.name, cus, clk_ghz);
   uint64_t* d_out = nullptr;
+  uint64_t* d_ticks = nullptr;
   const int max_blocks = cus * 8;
   CHECK(hipMalloc(&d_out, sizeof(uint64_t) * 256 * max_blocks));
+  CHECK(hipMalloc(&d_ticks, sizeof(uint64_t) * max_blocks));
+  std::vector<uint64_t> h_ticks(max_blocks);
   const bench benches[] = {
       {"v_mad_u64_u32", k_mad_u64_u32},   {"v_mad_u64_u32(dep chain)", k_mad_u64_u32_dep},
       {"v_mul_lo_u32", k_mul_lo_u32},     {"v_mul_hi_u32", k_mul_hi_u32},
@@ -147,30 +162,65 @@ int main() {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  // waves per SIMD: 1, 2, 4, 8  (blocks of 256 threads = 4 waves = one per SIMD)
-  std::printf("%-28s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD)\n", "instr",
-              "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
+  // waves per SIMD: 1, 2, 4, 8  (blocks of 256 threads = 4 waves = one per SIMD).  Per cell:
+  //   nominal = wall time x the 2.4 GHz of hipDeviceProp / wave-instructions per SIMD
+  //   shader  = s_memtime ticks of a wave / its instructions / waves per SIMD  (real cycles)
+  std::printf("%-26s | %-31s | %-31s | %s\n", "instr",
+              "nominal cyc @1,2,4,8 w/SIMD", "shader cyc @1,2,4,8 w/SIMD", "eff. clock GHz @8");
+  double clock_sum = 0, mad_cycles = 0, fma32_cycles = 0, mad_ns = 0, mad_clock = 0;
+  int clock_count = 0;
   for (const auto& b : benches) {
-    std::printf("%-28s", b.name);
+    std::printf("%-26s |", b.name);
+    double shader[4] = {0, 0, 0, 0}, eff = 0;
+    int col = 0;
     for (int wps : {1, 2, 4, 8}) {
       const int blocks = cus * wps;
-      hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, d_out, 1u);
+      hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, 1u);
       CHECK(hipDeviceSynchronize());
       CHECK(hipEventRecord(e0));
-      for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, d_out, 2u + r);
+      for (int r = 0; r < 3; ++r) {
+        hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, 2u + r);
+      }
       CHECK(hipEventRecord(e1));
       CHECK(hipEventSynchronize(e1));
       float ms = 0;
       CHECK(hipEventElapsedTime(&ms, e0, e1));
-      const bool dep = b.fn == k_mad_u64_u32_dep;
-      const double instrs_per_wave = 3.0 * kIters * 8;
-      // each SIMD ran `wps` waves
-      const double cycles = ms * 1e-3 * clk_ghz * 1e9;
-      std::printf(" %10.2f", cycles / (instrs_per_wave * wps));
-      (void)dep;
+      CHECK(hipMemcpy(h_ticks.data(), d_ticks, sizeof(uint64_t) * blocks, hipMemcpyDeviceToHost));
+      double tick_sum = 0, tick_max = 0;
+      for (int i = 0; i < blocks; ++i) {
+        tick_sum += static_cast<double>(h_ticks[i]);
+        if (static_cast<double>(h_ticks[i]) > tick_max) tick_max = static_cast<double>(h_ticks[i]);
+      }
+      const double instrs_per_wave = 1.0 * kIters * 8; // one launch
+      const double cycles = ms * 1e-3 * clk_ghz * 1e9 / 3.0;
+      std::printf(" %7.2f", cycles / (instrs_per_wave * wps));
+      // the longest-running wave spans (nearly) the whole launch, during which its SIMD issued
+      // the instructions of `wps` waves: real shader cycles per wave-instruction per SIMD
+      shader[col++] = tick_max / (instrs_per_wave * wps);
+      (void)tick_sum;
+      eff = tick_max / (ms * 1e-3 / 3.0) * 1e-9;
     }
-    std::printf("\n");
+    std::printf(" |");
+    for (int i = 0; i < 4; ++i) std::printf(" %7.2f", shader[i]);
+    std::printf(" | %6.2f\n", eff);
+    clock_sum += eff;
+    clock_count += 1;
+    if (b.fn == k_mad_u64_u32) {
+      mad_cycles = shader[3];
+      mad_clock = eff;
+      mad_ns = shader[3] / eff; // wall nanoseconds one SIMD needs per wave-instruction
+    }
+    if (b.fn == k_fma_f32) fma32_cycles = shader[3];
   }
+  (void)clock_sum;
+  (void)clock_count;
+  std::printf("CALIBRATION {\"effective_clock_hz\": %.4g, \"mad_u64_u32_cycles\": %.3f, "
+              "\"mad_u64_u32_ns_per_simd\": %.4f, \"fma_f32_cycles\": %.3f, \"source\": "
+              "\"tools/ubench/valu_rates.hip: s_memtime ticks of the longest wave per "
+              "wave-instruction at 8 waves per SIMD; clock = ticks / wall time under the "
+              "v_mad_u64_u32 load\"}\n",
+              mad_clock * 1e9, mad_cycles, mad_ns, fma32_cycles);
   CHECK(hipFree(d_out));
+  CHECK(hipFree(d_ticks));
   return 0;
 }
