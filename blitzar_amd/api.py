@@ -122,6 +122,16 @@ def load():
     lib.bzamd_ristretto255_generators_device.restype = None
     lib.bzamd_fixed_packed_multiexponentiation_device.argtypes = [vp, vp, vp, vp, cu, cu, vp, vp]
     lib.bzamd_fixed_packed_multiexponentiation_device.restype = None
+    lib.sxt_curve25519_prove_inner_product.argtypes = [vp, vp, vp, vp, u64, u64, vp, vp]
+    lib.sxt_curve25519_prove_inner_product.restype = None
+    lib.sxt_curve25519_verify_inner_product.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp, vp]
+    lib.sxt_curve25519_verify_inner_product.restype = ctypes.c_int
+    lib.bzamd_transcript_init.argtypes = [vp, ctypes.c_char_p, u64]
+    lib.bzamd_transcript_init.restype = None
+    lib.bzamd_num_devices.restype = ctypes.c_int
+    lib.bzamd_set_shard_min_bytes.argtypes = [u64]
+    lib.bzamd_set_shard_min_bytes.restype = None
+    lib.bzamd_accumulate_form.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -214,6 +224,48 @@ def get_one_commit(n):
     rc = load().sxt_curve25519_get_one_commit(_ptr(out), n)
     assert rc == 0
     return out
+
+
+def transcript_new(label):
+    """a fresh Merlin transcript (203 bytes) with the application label"""
+    raw = label.encode() if isinstance(label, str) else bytes(label)
+    out = np.zeros(203, dtype=np.uint8)
+    load().bzamd_transcript_init(_ptr(out), raw, len(raw))
+    return out
+
+
+def _rounds(n):
+    return max(int(n) - 1, 0).bit_length()
+
+
+def prove_inner_product(transcript, n, generators_offset, a_vector, b_vector):
+    """sxt_curve25519_prove_inner_product -> (l [rounds, 32], r [rounds, 32], ap [32], transcript)"""
+    t = np.ascontiguousarray(transcript, dtype=np.uint8).copy()
+    a = np.ascontiguousarray(a_vector, dtype=np.uint8).reshape(n, 32)
+    b = np.ascontiguousarray(b_vector, dtype=np.uint8).reshape(n, 32)
+    rounds = _rounds(n)
+    l = np.zeros((max(rounds, 1), 32), dtype=np.uint8)
+    r = np.zeros((max(rounds, 1), 32), dtype=np.uint8)
+    ap = np.zeros(32, dtype=np.uint8)
+    load().sxt_curve25519_prove_inner_product(_ptr(l), _ptr(r), _ptr(ap), _ptr(t), n,
+                                              generators_offset, _ptr(a), _ptr(b))
+    return l[:rounds], r[:rounds], ap, t
+
+
+def verify_inner_product(transcript, n, generators_offset, b_vector, product, a_commit, l_vector,
+                         r_vector, ap_value):
+    """sxt_curve25519_verify_inner_product -> (bool, transcript after)"""
+    t = np.ascontiguousarray(transcript, dtype=np.uint8).copy()
+    b = np.ascontiguousarray(b_vector, dtype=np.uint8).reshape(n, 32)
+    lv = np.ascontiguousarray(l_vector, dtype=np.uint8).reshape(-1, 32)
+    rv = np.ascontiguousarray(r_vector, dtype=np.uint8).reshape(-1, 32)
+    if lv.shape[0] == 0:
+        lv = rv = np.zeros((1, 32), np.uint8)
+    rc = load().sxt_curve25519_verify_inner_product(
+        _ptr(t), n, generators_offset, _ptr(b), _ptr(np.ascontiguousarray(product, np.uint8)),
+        _ptr(np.ascontiguousarray(a_commit, np.uint64)), _ptr(lv), _ptr(rv),
+        _ptr(np.ascontiguousarray(ap_value, np.uint8)))
+    return bool(rc), t
 
 
 class MultiexpHandle:

@@ -26,6 +26,7 @@ SOURCES = [
     "msm/msm_grumpkin.hip",
     "msm/context.hip",
     "generators/builtin.hip",
+    "proof/inner_product.hip",
     "api/capi.hip",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + ROOT,

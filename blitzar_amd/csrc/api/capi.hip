@@ -19,6 +19,8 @@
 #include "blitzar_amd/csrc/api/state.h"
 #include "blitzar_amd/csrc/fixed/dump.h"
 #include "blitzar_amd/csrc/fixed/handle.h"
+#include "blitzar_amd/csrc/proof/inner_product.h"
+#include "blitzar_amd/csrc/proof/transcript.h"
 #include "include/blitzar_amd.h"
 
 using namespace bz;
@@ -294,17 +296,13 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   return d_out;
 }
 
-// the Pedersen path of all five entry points
-void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequences,
-                         const sxt_sequence_descriptor* descriptors, const void* generators,
-                         generator_source source, u64 offset_generators,
-                         bool projective_out = false) {
-  if (num_sequences == 0) return; // reference: returns before touching anything
-  BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
-  api_state& st = state();
+// the Pedersen path of all five entry points; the caller holds st.api_mutex
+void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* commitments,
+                                u32 num_sequences, const sxt_sequence_descriptor* descriptors,
+                                const void* generators, generator_source source,
+                                u64 offset_generators, bool projective_out) {
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   const u32 out_stride = static_cast<u32>(projective_out ? vt.projective_size : vt.output_size);
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
 
   size_t scalar_bytes = 0;
   for (const auto& c : cc.cols) scalar_bytes += static_cast<size_t>(c.n) * c.row_stride;
@@ -450,6 +448,18 @@ long env_count(const char* name, long fallback) {
   return v;
 }
 
+void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequences,
+                         const sxt_sequence_descriptor* descriptors, const void* generators,
+                         generator_source source, u64 offset_generators,
+                         bool projective_out = false) {
+  if (num_sequences == 0) return; // reference: returns before touching anything
+  BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
+  api_state& st = state();
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
+                             offset_generators, projective_out);
+}
+
 int backend_from_environment(int backend) {
   const char* val = std::getenv("BLITZAR_BACKEND");
   if (val == nullptr) return backend;
@@ -463,6 +473,22 @@ int backend_from_environment(int backend) {
 } // namespace
 
 api_state* current_state() { return g_state; }
+
+namespace proof {
+void host_builtin_generators_unlocked(api_state& st, ed_point* out, u64 n, u64 offset) {
+  host_builtin_generators(st, out, n, offset);
+}
+void commit_column_unlocked(api_state& st, u8* out32, const u8* scalars, u64 n,
+                            const ed_point* generators) {
+  sxt_sequence_descriptor d{};
+  d.element_nbytes = 32;
+  d.n = n;
+  d.data = scalars;
+  d.is_signed = 0;
+  compute_commitments_locked(st, curve25519_vtable(), out32, 1, &d, generators,
+                             generator_source::host_api, 0, false);
+}
+} // namespace proof
 } // namespace bz
 
 extern "C" {
@@ -885,28 +911,60 @@ void bzamd_fixed_packed_multiexponentiation_device(void* res,
 }
 
 //--------------------------------------------------------------------------------------------------
-// out-of-scope provers: exported for link compatibility, abort when called
+// inner-product argument (proof/inner_product.hip); the sumcheck prover stays a link-compatible
+// stub that aborts when called
 //--------------------------------------------------------------------------------------------------
-void sxt_curve25519_prove_inner_product(struct sxt_ristretto255_compressed*,
-                                        struct sxt_ristretto255_compressed*,
-                                        struct sxt_curve25519_scalar*, struct sxt_transcript*,
-                                        uint64_t, uint64_t, const struct sxt_curve25519_scalar*,
-                                        const struct sxt_curve25519_scalar*) {
-  std::fprintf(stderr, "blitzar_amd: sxt_curve25519_prove_inner_product is outside the MSM path "
-                       "and not implemented\n");
-  std::abort();
+void sxt_curve25519_prove_inner_product(struct sxt_ristretto255_compressed* l_vector,
+                                        struct sxt_ristretto255_compressed* r_vector,
+                                        struct sxt_curve25519_scalar* ap_value,
+                                        struct sxt_transcript* transcript, uint64_t n,
+                                        uint64_t generators_offset,
+                                        const struct sxt_curve25519_scalar* a_vector,
+                                        const struct sxt_curve25519_scalar* b_vector) {
+  // validation: cbindings/inner_product_proof.cc:35-57
+  BZ_RELEASE_ASSERT(transcript != nullptr, "transcript must not be null");
+  BZ_RELEASE_ASSERT(ap_value != nullptr, "ap_value must not be null");
+  BZ_RELEASE_ASSERT(b_vector != nullptr, "b_vector must not be null");
+  BZ_RELEASE_ASSERT(a_vector != nullptr, "a_vector must not be null");
+  BZ_RELEASE_ASSERT(n > 0, "a_vector and b_vector lengths must be greater than zero");
+  BZ_RELEASE_ASSERT(n == 1 || (l_vector != nullptr && r_vector != nullptr),
+                    "l_vector and r_vector must not be null when n is bigger than one");
+  BZ_RELEASE_ASSERT(n <= (uint64_t{1} << 30), "inner products are limited to 2^30 elements");
+  api_state& st = state();
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  proof::prove_inner_product(st, reinterpret_cast<u8*>(l_vector), reinterpret_cast<u8*>(r_vector),
+                             ap_value->bytes, transcript, n, generators_offset,
+                             reinterpret_cast<const u8*>(a_vector),
+                             reinterpret_cast<const u8*>(b_vector));
 }
 
-int sxt_curve25519_verify_inner_product(struct sxt_transcript*, uint64_t, uint64_t,
-                                        const struct sxt_curve25519_scalar*,
-                                        const struct sxt_curve25519_scalar*,
-                                        const struct sxt_ristretto255*,
-                                        const struct sxt_ristretto255_compressed*,
-                                        const struct sxt_ristretto255_compressed*,
-                                        const struct sxt_curve25519_scalar*) {
-  std::fprintf(stderr, "blitzar_amd: sxt_curve25519_verify_inner_product is outside the MSM path "
-                       "and not implemented\n");
-  std::abort();
+int sxt_curve25519_verify_inner_product(struct sxt_transcript* transcript, uint64_t n,
+                                        uint64_t generators_offset,
+                                        const struct sxt_curve25519_scalar* b_vector,
+                                        const struct sxt_curve25519_scalar* product,
+                                        const struct sxt_ristretto255* a_commit,
+                                        const struct sxt_ristretto255_compressed* l_vector,
+                                        const struct sxt_ristretto255_compressed* r_vector,
+                                        const struct sxt_curve25519_scalar* ap_value) {
+  // validation: cbindings/inner_product_proof.cc:62-91 (aborts on null inputs even though the
+  // proof itself is untrusted, like the reference)
+  BZ_RELEASE_ASSERT(transcript != nullptr, "transcript must not be null");
+  BZ_RELEASE_ASSERT(ap_value != nullptr, "ap_value must not be null");
+  BZ_RELEASE_ASSERT(product != nullptr, "product must not be null");
+  BZ_RELEASE_ASSERT(a_commit != nullptr, "a_commit must not be null");
+  BZ_RELEASE_ASSERT(b_vector != nullptr, "b_vector must not be null");
+  BZ_RELEASE_ASSERT(n > 0, "b_vector length must be greater than zero");
+  BZ_RELEASE_ASSERT(n == 1 || (l_vector != nullptr && r_vector != nullptr),
+                    "l_vector and r_vector must not be null when n is bigger than one");
+  BZ_RELEASE_ASSERT(n <= (uint64_t{1} << 30), "inner products are limited to 2^30 elements");
+  api_state& st = state();
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  return proof::verify_inner_product(st, transcript, n, generators_offset,
+                                     reinterpret_cast<const u8*>(b_vector), product->bytes,
+                                     a_commit, reinterpret_cast<const u8*>(l_vector),
+                                     reinterpret_cast<const u8*>(r_vector), ap_value->bytes)
+             ? 1
+             : 0;
 }
 
 void sxt_prove_sumcheck(void*, void*, unsigned, const struct sumcheck_descriptor*, void*, void*) {
@@ -931,6 +989,12 @@ int bzamd_num_devices(void) {
 }
 
 void bzamd_set_shard_min_bytes(uint64_t bytes) { g_shard_min_bytes.store(bytes); }
+
+void bzamd_transcript_init(struct sxt_transcript* transcript, const char* label,
+                           uint64_t label_len) {
+  BZ_RELEASE_ASSERT(transcript != nullptr && (label != nullptr || label_len == 0), "null argument");
+  proof::transcript::init(transcript, std::string_view{label, label_len});
+}
 
 int bzamd_accumulate_form(void) {
   // curve25519 caller generators are normalised to Z = 1 on every call (batched inversion)

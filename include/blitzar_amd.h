@@ -33,6 +33,12 @@ int bzamd_active_backend(void);
 int bzamd_num_devices(void);
 /* calls with fewer scalar bytes than this stay on one device (default 1 MiB) */
 void bzamd_set_shard_min_bytes(uint64_t bytes);
+/* A fresh Merlin transcript with the application's domain-separation label: the 203 bytes a
+ * caller hands to sxt_curve25519_prove_inner_product / _verify_inner_product (the reference leaves
+ * their construction to the caller's Merlin implementation; Rust callers transmute
+ * merlin::Transcript, prft::transcript{label} in C++). */
+void bzamd_transcript_init(struct sxt_transcript* transcript, const char* label,
+                           uint64_t label_len);
 /* addition formula k_accumulate runs for curve25519 caller generators: 1 = Z = 1 addends (7 field
  * products, generators normalised per call by a batched inversion), 0 = projective (8 products) */
 int bzamd_accumulate_form(void);

@@ -30,6 +30,11 @@ FLAGS = ["-std=gnu++2b", "-O2", "-DNDEBUG", "-w", "-fPIC", "-I" + os.path.join(H
          "-I" + REF, "-include", "cstdint", "-include", "concepts", "-include",
          "initializer_list", "-include", "cstddef", "-include", "compare"]
 INC = re.compile(r'^\s*#\s*include\s+"(sxt/[^"]+)"', re.M)
+# translation units of the closure that hold CUDA kernels (`__global__`, `<<<>>>`) and cannot be
+# compiled on the host; the drivers define what they need from them (ref_inner_product.cc)
+SKIP = {"sxt/scalar25/operation/inner_product.cc", "sxt/base/device/state.cc",
+        "sxt/base/device/property.cc", "sxt/base/log/log_impl.cc", "sxt/base/log/setup.cc"}
+DRIVERS = ["ref_driver.cc", "ref_inner_product.cc"]
 
 
 def closure(root_file):
@@ -47,7 +52,7 @@ def closure(root_file):
                 raise SystemExit(f"missing reference header {h}")
             todo.append(hp)
             cc = hp[:-2] + ".cc"
-            if os.path.exists(cc):
+            if os.path.exists(cc) and os.path.relpath(cc, REF) not in SKIP:
                 srcs.append(cc)
                 todo.append(cc)
     return sorted(set(srcs))
@@ -67,16 +72,16 @@ def main():
         print(f"[oracle/_ref] {REF} not present; keeping prebuilt artefacts (if any)")
         return 0
     os.makedirs(OBJ, exist_ok=True)
-    driver = os.path.join(HERE, "ref_driver.cc")
-    srcs = closure(driver)
+    drivers = [os.path.join(HERE, d) for d in DRIVERS]
+    srcs = sorted(set(s for d in drivers for s in closure(d)))
     lib = os.path.join(OUT, "libblitzar_ref.so")
     if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s)
-                                   for s in srcs + [driver, __file__]):
+                                   for s in srcs + drivers + [__file__]):
         print(f"[oracle/_ref] up to date ({len(srcs)} reference TUs)")
         return 0
     with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
-        objs = list(ex.map(compile_one, srcs + [driver]))
-    subprocess.run([CXX, "-shared", "-o", lib, *objs], check=True)
+        objs = list(ex.map(compile_one, srcs + drivers))
+    subprocess.run([CXX, "-shared", "-Wl,-z,defs", "-o", lib, *objs], check=True)
     print(f"[oracle/_ref] built {lib} from {len(srcs)} reference TUs")
     return 0
 

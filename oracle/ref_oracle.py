@@ -193,3 +193,57 @@ def partition_table(curve_id, window_width, generators_projective):
     getattr(lib(), f"ref_{pfx}_partition_table")(_p(out), ctypes.c_uint(window_width), _p(g),
                                                  ctypes.c_uint(n))
     return out
+
+
+#--------------------------------------------------------------------------------------------------
+# inner-product argument (oracle/ref/ref_inner_product.cc: the reference's own prover / verifier)
+#--------------------------------------------------------------------------------------------------
+def transcript_new(label):
+    """prft::transcript{label}: the 203-byte Merlin state handed to the C API"""
+    out = np.zeros(203, dtype=np.uint8)
+    raw = label.encode() if isinstance(label, str) else bytes(label)
+    lib().ref_transcript_new(_p(out), ctypes.c_char_p(raw), ctypes.c_uint64(len(raw)))
+    return out
+
+
+def _rounds(n):
+    return max(int(n) - 1, 0).bit_length()
+
+
+def ip_prove(transcript, n, generators_offset, a_vector, b_vector):
+    """-> (l_vector [rounds, 32], r_vector [rounds, 32], ap_value [32], transcript after)"""
+    t = np.ascontiguousarray(transcript, dtype=np.uint8).copy()
+    a = np.ascontiguousarray(a_vector, dtype=np.uint8).reshape(n, 32)
+    b = np.ascontiguousarray(b_vector, dtype=np.uint8).reshape(n, 32)
+    rounds = _rounds(n)
+    l = np.zeros((max(rounds, 1), 32), dtype=np.uint8)
+    r = np.zeros((max(rounds, 1), 32), dtype=np.uint8)
+    ap = np.zeros(32, dtype=np.uint8)
+    lib().ref_ip_prove(_p(l), _p(r), _p(ap), _p(t), ctypes.c_uint64(n),
+                       ctypes.c_uint64(generators_offset), _p(a), _p(b))
+    return l[:rounds], r[:rounds], ap, t
+
+
+def ip_verify(transcript, n, generators_offset, b_vector, product, a_commit, l_vector, r_vector,
+              ap_value):
+    t = np.ascontiguousarray(transcript, dtype=np.uint8).copy()
+    b = np.ascontiguousarray(b_vector, dtype=np.uint8).reshape(n, 32)
+    lv = np.ascontiguousarray(l_vector, dtype=np.uint8).reshape(-1, 32)
+    rv = np.ascontiguousarray(r_vector, dtype=np.uint8).reshape(-1, 32)
+    if lv.shape[0] == 0:
+        lv = np.zeros((1, 32), np.uint8)
+        rv = np.zeros((1, 32), np.uint8)
+    lib().ref_ip_verify.restype = ctypes.c_int
+    rc = lib().ref_ip_verify(_p(t), ctypes.c_uint64(n), ctypes.c_uint64(generators_offset), _p(b),
+                             _p(np.ascontiguousarray(product, dtype=np.uint8)),
+                             _p(np.ascontiguousarray(a_commit, dtype=np.uint64)), _p(lv), _p(rv),
+                             _p(np.ascontiguousarray(ap_value, dtype=np.uint8)))
+    return bool(rc), t
+
+
+def s25_inner_product(a_vector, b_vector):
+    a = np.ascontiguousarray(a_vector, dtype=np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(b_vector, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros(32, dtype=np.uint8)
+    lib().ref_s25_inner_product(_p(out), _p(a), _p(b), ctypes.c_uint64(min(a.shape[0], b.shape[0])))
+    return out
