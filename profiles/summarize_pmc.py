@@ -67,15 +67,34 @@ def main():
                 act = sum(c["SQ_ACTIVE_INST_VALU"]) / len(c["SQ_ACTIVE_INST_VALU"])
                 cyc = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8
                 valu_busy = 4 * act / (1024 * cyc)
+            # gfx950 correction of the guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies a
+            # 128-byte request of 16-byte-per-lane loads as 64 bytes -> x 2.  Calibrated in the
+            # same run on a kernel with known bytes: k_prepare_addends reads n x 160 B and writes
+            # n x 128 B (n = 2^20: 167.8 MB / 134.2 MB).
+            cal = {}
+            prep = [k for k in counters if k.startswith("k_prepare_addends<")]
+            if prep and "FETCH_SIZE" in counters[prep[0]]:
+                pf = sum(counters[prep[0]]["FETCH_SIZE"]) / len(counters[prep[0]]["FETCH_SIZE"])
+                pw = sum(counters[prep[0]]["WRITE_SIZE"]) / len(counters[prep[0]]["WRITE_SIZE"])
+                cal = {"kernel": prep[0], "known_read_bytes": (1 << 20) * 160,
+                       "fetch_size_bytes_raw": pf * 1024, "known_write_bytes": (1 << 20) * 128,
+                       "write_size_bytes_raw": pw * 1024,
+                       "read_factor": (1 << 20) * 160 / (pf * 1024),
+                       "write_factor": (1 << 20) * 128 / (pw * 1024)}
             out = {"kernel": acc[0], "fetch_kib": f, "write_kib": w, "valu_busy": valu_busy,
-                   "k_accumulate_bytes_per_launch": (f + w) * 1024,
-                   "note": "FETCH_SIZE + WRITE_SIZE (KiB) x 1024, separate --pmc passes, raw "
-                           "counter values.  The gathers are per-lane 16-byte loads of random "
-                           "128-byte aligned rows; FETCH_SIZE tallies a 128-byte request as 64 "
-                           "bytes on gfx950 (MI355X_MICROARCH.md, HBM), so the read side may be up "
-                           "to 2x this figure: 17.8 M rows x 128 B = 2.3 GB is the expected gather "
-                           "volume, most of it served by the 256 MiB Infinity Cache, which the "
-                           "counter does not exclude"}
+                   "k_accumulate_bytes_per_launch": (2 * f + w) * 1024,
+                   "raw_bytes_per_launch": (f + w) * 1024,
+                   "calibration": cal,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                             "tools/prof/run_pmc.sh) of `python bench.py` on MI355X, summarised "
+                             "by profiles/summarize_pmc.py from " + root,
+                   "note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024): "
+                           "the gfx950 correction of MI355X_MICROARCH.md (HBM), confirmed in the "
+                           "same run on k_prepare_addends whose bytes are known (see "
+                           "`calibration`).  The bucket method gathers every 128-byte addend once "
+                           "per window: 16 x 2^20 x 128 B = 2.15 GB plus 0.2 GB of indices and "
+                           "bucket writes against 0.20 GB algorithmic; the addend table (128 MiB) "
+                           "sits in the 256 MiB Infinity Cache, whose hits these counters include"}
             if len(sys.argv) > 2:
                 with open(sys.argv[2], "w") as fh:
                     json.dump(out, fh, indent=1)
