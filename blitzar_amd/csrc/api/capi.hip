@@ -845,7 +845,20 @@ void sxt_multiexp_handle_write_to_file(const struct sxt_multiexp_handle* handle,
   BZ_RELEASE_ASSERT(h != nullptr, "handle is null");
   std::FILE* f = std::fopen(filename, "wb");
   BZ_RELEASE_ASSERT(f != nullptr, "failed to open partition table file for writing");
-  const bool ok = h->vt->write_partition_table(f, h->window_width, h->host_projective.data(), h->n);
+  // GPU backend: the 2^w subset sums of every window are built on the device
+  // (fixed/partition_table_device.h); wider windows than 16 bits and the cpu backend use the
+  // reference's serial host recurrence
+  api_state& st = state();
+  bool ok = false;
+  if (st.backend == SXT_GPU_BACKEND && h->window_width <= 16 && h->n > 0) {
+    std::lock_guard<std::mutex> api_lock(st.api_mutex);
+    device_state& ds = st.primary();
+    ds.activate();
+    ok = h->vt->write_partition_table_device(f, h->window_width, h->host_projective.data(), h->n,
+                                             ds.stream);
+  } else {
+    ok = h->vt->write_partition_table(f, h->window_width, h->host_projective.data(), h->n);
+  }
   // a full disk must not leave a silently truncated table behind
   BZ_RELEASE_ASSERT(std::fclose(f) == 0 && ok, "short write to the partition table file");
 }

@@ -71,6 +71,36 @@ struct ed25519_msm {
   }
   // engine point -> caller generator layout (sxt_ristretto255)
   BZ_HD static void store_api_generator(u8* out, const point& p) { store_projective(out, p); }
+  // shared inversions (Montgomery's trick over a workgroup: msm/kernels.h tree_products /
+  // tree_inverses; k_prepare_addends_batched, fixed/partition_table_device.h)
+  using batch_fe = fe29;
+  BZ_HD static fe29 batch_one() { return f29::one(); }
+  BZ_HD static fe29 batch_mul(const fe29& a, const fe29& b) { return f29::mul(a, b); }
+  // the coordinate to invert for the affine form; edwards points never have Z = 0
+  BZ_HD static fe29 batch_z(const point& p, bool& is_identity) {
+    is_identity = false;
+    return p.Z;
+  }
+  // compact table entry {x, y, x y} as 5 x 51-bit limbs (sxt/curve21/type/compact_element.h:
+  // 30-38); the limbs the reference's field products leave are the canonical digits of the value
+  // (checked against the reference's own tables, tests/test_oracle.py)
+  static constexpr size_t compact_size = 120;
+  BZ_HD static void store_compact(u8* out, const point& p, const fe29& zinv, bool) {
+    const fe29 x = f29::mul(p.X, zinv), y = f29::mul(p.Y, zinv);
+    const fe51 c[3] = {f29::to_fe51(x), f29::to_fe51(y), f29::to_fe51(f29::mul(x, y))};
+    u64* o = reinterpret_cast<u64*>(out);
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < 5; ++i) o[5 * k + i] = c[k].v[i];
+  }
+#if defined(__HIPCC__)
+  // 1 / z by the 64 lanes of one wavefront (every lane passes the same z and gets the result):
+  // z^(p - 2) = (z^(2^252 - 3))^8 * z^3, the long exponentiation row-parallel (curve/ed16_wave.h)
+  __device__ static fe29 batch_wave_invert(const fe29& z) {
+    const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
+    const fe29 t = ed16w::pow22523(c, z);
+    return f29::mul(f29::sqn(t, 3), f29::mul(f29::sq(z), z));
+  }
+#endif
   // k_horner's dependent chain, run by one wavefront that holds the single accumulator spread over
   // its 64 lanes (curve/ed16_wave.h: a row of 16 lanes per coordinate, a limb per lane):
   //   2^(c n) * acc + sum_{w < n} 2^(c w) * window_sums[w * stride]   (acc absent: top window first)
@@ -144,9 +174,6 @@ struct ed25519_niels_msm : ed25519_msm {
   // batched normalisation (k_prepare_addends_batched): the inversions of a workgroup's generators
   // share one exponentiation
   static constexpr bool has_batched_prepare = true;
-  using batch_fe = fe29;
-  BZ_HD static fe29 batch_one() { return f29::one(); }
-  BZ_HD static fe29 batch_mul(const fe29& a, const fe29& b) { return f29::mul(a, b); }
   BZ_HD static fe29 batch_load_z(const void* api_generators, u64 i) {
     return f29::from_fe51(static_cast<const ed_point*>(api_generators)[i].Z);
   }
@@ -161,15 +188,6 @@ struct ed25519_niels_msm : ed25519_msm {
     for (int k = 0; k < 5; ++k) n.pad[k] = 0;
     return n;
   }
-#if defined(__HIPCC__)
-  // 1 / z by the 64 lanes of one wavefront (every lane passes the same z and gets the result):
-  // z^(p - 2) = (z^(2^252 - 3))^8 * z^3, the long exponentiation row-parallel (curve/ed16_wave.h)
-  __device__ static fe29 batch_wave_invert(const fe29& z) {
-    const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
-    const fe29 t = ed16w::pow22523(c, z);
-    return f29::mul(f29::sqn(t, 3), f29::mul(f29::sq(z), z));
-  }
-#endif
 };
 
 // Weierstrass curves: the kernels compute on the unsaturated-limb Montgomery representation
@@ -209,6 +227,34 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
     return acc;
   }
 #endif
+
+  // shared inversions (Montgomery's trick over a workgroup)
+  using F29 = typename G29::F;
+  using batch_fe = typename G29::fe;
+  BZ_HD static batch_fe batch_one() { return F29::one(); }
+  BZ_HD static batch_fe batch_mul(const batch_fe& a, const batch_fe& b) { return F29::mul(a, b); }
+  BZ_HD static batch_fe batch_z(const point& p, bool& is_identity) {
+    is_identity = F29::is_zero(p.Z);
+    return is_identity ? F29::one() : p.Z;
+  }
+  // every lane inverts the same value: uniform control flow, the cost of one lane
+  BZ_HD static batch_fe batch_wave_invert(const batch_fe& z) { return F29::invert(z); }
+  // compact table entry {X, Y} in the ABI's Montgomery form, identity = {X[N-1] = 2^64 - 1, Y = R}
+  // (sxt/curve_bng1/type/compact_element.h:26-38)
+  static constexpr size_t compact_size = 16 * N64;
+  BZ_HD static void store_compact(u8* out, const point& p, const batch_fe& zinv, bool is_identity) {
+    u64* o = reinterpret_cast<u64*>(out);
+    if (is_identity) {
+      const typename G64::F::fe one = G64::F::one();
+      for (int k = 0; k < N64; ++k) {
+        o[k] = k == N64 - 1 ? ~u64{0} : 0;
+        o[N64 + k] = one.v[k];
+      }
+      return;
+    }
+    F29::to_mont64(o, F29::mul(p.X, zinv));
+    F29::to_mont64(o + N64, F29::mul(p.Y, zinv));
+  }
 
   BZ_HD static point identity() { return G29::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return G29::add(a, b); }

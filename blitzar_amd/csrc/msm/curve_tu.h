@@ -4,6 +4,7 @@
 #include "blitzar_amd/csrc/msm/dispatch.h"
 #include "blitzar_amd/csrc/msm/engine.h"
 #include "blitzar_amd/csrc/fixed/partition_table.h"
+#include "blitzar_amd/csrc/fixed/partition_table_device.h"
 #include "blitzar_amd/csrc/msm/host_backend.h"
 
 namespace bz {
@@ -164,6 +165,7 @@ template <class C, class R = C, class H = C> struct curve_tu {
                                  &curve_tu::prepare_resident_projective,
                                  sizeof(typename compact_ops<H>::compact),
                                  &write_partition_table<H>,
+                                 &write_partition_table_device<H>,
                                  &read_partition_generators<H>,
                                  &write_compact_generators<H>,
                                  C::reference_element_name,

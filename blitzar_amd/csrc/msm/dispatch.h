@@ -54,6 +54,9 @@ struct curve_vtable {
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
   bool (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);
+  // the same file built on the current device (window widths up to 16)
+  bool (*write_partition_table_device)(std::FILE* f, unsigned window_width, const void* projective,
+                                       u64 n, hipStream_t stream);
   bool (*read_partition_generators)(std::FILE* f, unsigned& window_width,
                                     std::vector<u8>& projective_out, u64& n);
   // BLITZAR_DUMP_DIR recording (fixed/dump.h): compact generators + the reference's type names

@@ -81,12 +81,39 @@ template <u32 N, class F> __device__ __forceinline__ void static_for(F&& f) {
 #ifndef BZ_BATCH_PREPARE_WAVES
 #define BZ_BATCH_PREPARE_WAVES 1
 #endif
+// Montgomery's trick across a workgroup of T lanes (T a power of two): `tree` has 2 T entries in
+// heap order (root 1, leaf T + lane).  tree_products: leaves -> products of every subtree, root in
+// tree[1].  tree_inverses: with tree[1] replaced by the inverse of the root, every node becomes
+// the inverse of its subtree's product (children get inv * sibling); the leaves end up holding the
+// inverse of each lane's own product.
+template <class C, u32 T>
+__device__ __forceinline__ void tree_products(typename C::batch_fe* tree, u32 tid) {
+  __syncthreads();
+  for (u32 s = T / 2; s >= 1; s >>= 1) {
+    if (tid < s) tree[s + tid] = C::batch_mul(tree[2 * (s + tid)], tree[2 * (s + tid) + 1]);
+    __syncthreads();
+  }
+}
+template <class C, u32 T>
+__device__ __forceinline__ void tree_inverses(typename C::batch_fe* tree, u32 tid) {
+  __syncthreads();
+  for (u32 s = 1; s < T; s <<= 1) {
+    if (tid < s) {
+      const u32 i = s + tid;
+      const typename C::batch_fe inv = tree[i], left = tree[2 * i], right = tree[2 * i + 1];
+      tree[2 * i] = C::batch_mul(inv, right);
+      tree[2 * i + 1] = C::batch_mul(inv, left);
+    }
+    __syncthreads();
+  }
+}
+
 template <class C>
 __global__ void __launch_bounds__(kBatchPrepareThreads, BZ_BATCH_PREPARE_WAVES)
     k_prepare_addends_batched(typename C::addend* __restrict__ addends,
                               const void* __restrict__ api_generators, u64 n) {
   using fe = typename C::batch_fe;
-  __shared__ fe tree[2 * kBatchPrepareThreads]; // heap order: root 1, leaves 256 + lane
+  __shared__ fe tree[2 * kBatchPrepareThreads];
   const u32 tid = threadIdx.x;
   const u64 base = static_cast<u64>(blockIdx.x) * kBatchPrepareThreads * kBatchPreparePoints;
   fe z[kBatchPreparePoints], prefix[kBatchPreparePoints];
@@ -101,26 +128,12 @@ __global__ void __launch_bounds__(kBatchPrepareThreads, BZ_BATCH_PREPARE_WAVES)
     }
   });
   tree[kBatchPrepareThreads + tid] = prefix[kBatchPreparePoints - 1];
-  __syncthreads();
-  for (u32 s = kBatchPrepareThreads / 2; s >= 1; s >>= 1) {
-    if (tid < s) tree[s + tid] = C::batch_mul(tree[2 * (s + tid)], tree[2 * (s + tid) + 1]);
-    __syncthreads();
-  }
+  tree_products<C, kBatchPrepareThreads>(tree, tid);
   if (tid < 64) {
     const fe inv = C::batch_wave_invert(tree[1]); // all 64 lanes cooperate, all get the result
     if (tid == 0) tree[1] = inv;
   }
-  __syncthreads();
-  // node i holds the inverse of its subtree's product; its children get inv * (the sibling)
-  for (u32 s = 1; s < kBatchPrepareThreads; s <<= 1) {
-    if (tid < s) {
-      const u32 i = s + tid;
-      const fe inv = tree[i], left = tree[2 * i], right = tree[2 * i + 1];
-      tree[2 * i] = C::batch_mul(inv, right);
-      tree[2 * i + 1] = C::batch_mul(inv, left);
-    }
-    __syncthreads();
-  }
+  tree_inverses<C, kBatchPrepareThreads>(tree, tid);
   fe inv = tree[kBatchPrepareThreads + tid];
   static_for<kBatchPreparePoints>([&](auto jc) {
     constexpr u32 j = kBatchPreparePoints - 1 - decltype(jc)::value;

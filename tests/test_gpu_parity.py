@@ -429,3 +429,28 @@ def test_repeated_and_cancelling_generators(gpu_backend, oracle, curve_id):
     assert np.array_equal(got, want)
     assert np.array_equal(got[2], oracle.commit(curve_id, [(np.zeros((0, 1), np.uint8), False)],
                                                 gens)[0])  # cancels to the identity encoding
+
+
+@pytest.mark.parametrize("curve_id,width,n", [(0, 4, 11), (0, 16, 20), (0, 11, 30), (1, 8, 9),
+                                              (2, 16, 17), (3, 1, 5), (3, 13, 14)])
+def test_partition_table_built_on_device(gpu_backend, oracle, curve_id, width, n, tmp_path,
+                                         monkeypatch):
+    """sxt_multiexp_handle_write_to_file on the GPU backend builds the 2^w subset sums of every
+    window on the device (fixed/partition_table_device.h: half tables + one addition per entry,
+    inversions shared two levels deep); the file must equal the reference's own
+    compute_partition_table output byte for byte, identity padding and sentinels included"""
+    from oracle import fixed_base
+    monkeypatch.setenv("BLITZAR_PARTITION_WINDOW_WIDTH", str(width))
+    gens = util.generators_for(curve_id, n)  # index 5 is the identity for the Weierstrass curves
+    proj = gens if curve_id == 0 else oracle.affine_to_projective(curve_id, gens)
+    before = gpu_backend.load().bzamd_kernel_launch_count()
+    h = gpu_backend.MultiexpHandle(curve_id, proj)
+    path = str(tmp_path / "table.bin")
+    h.write_to_file(path)
+    h.close()
+    assert gpu_backend.load().bzamd_kernel_launch_count() >= before + 4
+    with open(path, "rb") as fh:
+        data = fh.read()
+    want = fixed_base.PartitionTable(curve_id, proj, width).file_bytes()
+    assert len(data) == len(want)
+    assert data == want
