@@ -418,11 +418,13 @@ def main():
         for _ in range(args.warmup):
             lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
         torch.cuda.synchronize()
+        clock2 = StageClock(lib, args.steps)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
         torch.cuda.synchronize()
         resident_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        resident_stages, _ = clock2.collect(args.steps)
         assert np.array_equal(out2.cpu().numpy(), timed_output), "resident path disagrees"
         lib.bzamd_generators_free(handle)
 
@@ -479,7 +481,12 @@ def main():
         if verified:
             result["verified"] = verified
         if resident_ms is not None:
+            # the same column against a generator set registered once (bzamd_generators_*): Z = 1
+            # addends and, for sets of 2^14 generators or more, window tables (2^(16 w) g_i
+            # resident: one bucket set for all windows, no Horner chain)
             result["resident_generators_ms_per_step"] = resident_ms
+            result["resident_generators_stage_ms"] = {k: round(v, 4)
+                                                      for k, v in resident_stages.items()}
         if calls > 0:
             result["stage_ms"] = {k: round(v, 4) for k, v in per_call.items()}
             alg_bytes = n * (nbytes + gen_bytes)

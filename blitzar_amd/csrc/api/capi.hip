@@ -49,11 +49,9 @@ void init_host_generators(api_state& st, u64 n) {
       ds.activate();
       ed_point* d_raw = nullptr;
       BZ_HIP_CHECK(hipMalloc(&d_raw, sizeof(ed_point) * n));
-      BZ_HIP_CHECK(hipMalloc(&ds.d_builtin_addends, curve25519_vtable().resident_addend_size * n));
       builtin_generators_enqueue(d_raw, 0, n, ds.stream);
       g_kernel_launches += 1;
-      curve25519_vtable().prepare_resident(ds.d_builtin_addends, d_raw, n, ds.stream);
-      g_kernel_launches += 1;
+      ds.builtin.build(curve25519_vtable(), d_raw, false, n, ds.stream);
       if (ds.slot == 0) {
         BZ_HIP_CHECK(hipMemcpyAsync(st.host_generators.data(), d_raw, sizeof(ed_point) * n,
                                     hipMemcpyDeviceToHost, ds.stream));
@@ -238,6 +236,7 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
 
   const void* d_addends = nullptr;
   bool resident = false;
+  window_table tables{};
   if (gens.source == generator_source::host_api) {
     u8* d_api = ds.io.take<u8>(vt.api_generator_size * longest + 32);
     void* prepared = ds.io.take<u8>(vt.addend_size * (longest + 1));
@@ -251,10 +250,14 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
     d_addends = prepared;
   } else if (gens.offset <= st.host_generators.size() &&
              longest <= st.host_generators.size() - gens.offset &&
-             ds.d_builtin_addends != nullptr) {
-    d_addends = static_cast<const char*>(ds.d_builtin_addends) +
-                vt.resident_addend_size * gens.offset;
+             ds.builtin.d_addends != nullptr) {
+    d_addends = ds.builtin.rows_from(gens.offset, vt.resident_addend_size);
     resident = true;
+    // the window-table slices stay `stride` apart; rows of a slice past the set's end are only
+    // ever paired with zero digits
+    if (ds.builtin.tables() != nullptr && longest <= ds.builtin.shape.stride - gens.offset) {
+      tables = ds.builtin.shape;
+    }
   } else {
     // beyond the init-time cache: derived on the fly for any offset, like the reference
     // (precomputed_generators.cc:56-91)
@@ -287,7 +290,8 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
     const std::vector<host_column> chunk(cols.begin() + begin, cols.begin() + end);
     u8* out_k = d_out + begin * static_cast<size_t>(out_stride);
     if (resident) {
-      vt.msm_resident(*ds.ctx, out_k, out_stride, projective_out, chunk, d_addends, ds.stream);
+      vt.msm_resident(*ds.ctx, out_k, out_stride, projective_out, chunk, d_addends, ds.stream,
+                      tables.windows != 0 ? &tables : nullptr);
     } else {
       vt.msm(*ds.ctx, out_k, out_stride, projective_out, chunk, d_addends, nullptr, ds.stream);
     }
@@ -656,16 +660,13 @@ void handle_make_resident(multiexp_handle& h) {
     device_state& ds = *dsp;
     ds.activate();
     void* d_proj = nullptr;
-    void* d_addends = nullptr;
     BZ_HIP_CHECK(hipMalloc(&d_proj, bytes));
-    BZ_HIP_CHECK(hipMalloc(&d_addends, h.vt->resident_addend_size * (h.n + 1)));
     BZ_HIP_CHECK(hipMemcpyAsync(d_proj, h.host_projective.data(), bytes, hipMemcpyHostToDevice,
                                 ds.stream));
-    h.vt->prepare_resident_projective(d_addends, d_proj, h.n, ds.stream);
-    g_kernel_launches += 1;
-    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+    resident_table table;
+    table.build(*h.vt, d_proj, true, h.n, ds.stream);
     BZ_HIP_CHECK(hipFree(d_proj));
-    h.d_addends.push_back(d_addends);
+    h.tables.push_back(table);
     h.devices.push_back(ds.device);
   }
   st.primary().activate();
@@ -716,10 +717,10 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
     BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
     int dev = 0;
     BZ_HIP_CHECK(hipGetDevice(&dev));
-    const void* d_addends = h.addends_on(dev);
-    BZ_RELEASE_ASSERT(d_addends != nullptr, "the handle has no addends on the current device");
+    const resident_table* table = h.table_on(dev);
+    BZ_RELEASE_ASSERT(table != nullptr, "the handle has no addends on the current device");
     h.vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(res), out_stride, true,
-                       cols, d_addends, caller_stream);
+                       cols, table->d_addends, caller_stream, table->tables());
     return;
   }
   std::lock_guard<std::mutex> api_lock(st.api_mutex);
@@ -797,7 +798,8 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
       c.row_stride = span;
     }
     u8* d_out = ds.io.take<u8>(out_bytes);
-    h.vt->msm_resident(*ds.ctx, d_out, out_stride, true, mine, h.d_addends[ds.slot], ds.stream);
+    h.vt->msm_resident(*ds.ctx, d_out, out_stride, true, mine, h.tables[ds.slot].d_addends,
+                       ds.stream, h.tables[ds.slot].tables());
     BZ_HIP_CHECK(hipMemcpyAsync(out + r.begin * static_cast<size_t>(out_stride), d_out, out_bytes,
                                 hipMemcpyDeviceToHost, ds.stream));
     BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
@@ -866,12 +868,12 @@ void sxt_multiexp_handle_write_to_file(const struct sxt_multiexp_handle* handle,
 void sxt_multiexp_handle_free(struct sxt_multiexp_handle* handle) {
   auto* h = reinterpret_cast<multiexp_handle*>(handle);
   if (h == nullptr) return;
-  if (!h->d_addends.empty()) {
+  if (!h->tables.empty()) {
     int current = 0;
     (void)hipGetDevice(&current);
-    for (size_t k = 0; k < h->d_addends.size(); ++k) {
+    for (size_t k = 0; k < h->tables.size(); ++k) {
       (void)hipSetDevice(h->devices[k]);
-      (void)hipFree(h->d_addends[k]);
+      h->tables[k].release();
     }
     (void)hipSetDevice(current);
   }
@@ -1010,8 +1012,9 @@ void bzamd_transcript_init(struct sxt_transcript* transcript, const char* label,
 }
 
 int bzamd_accumulate_form(void) {
-  // curve25519 caller generators are normalised to Z = 1 on every call (batched inversion)
-  return curve25519_vtable().addend_size == sizeof(ed29_niels) ? 1 : 0;
+  // curve25519 caller generators keep their projective form (msm/msm_curve25519.hip: the per-call
+  // normalisation was measured and rejected); resident sets use the Z = 1 form
+  return 0;
 }
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
@@ -1112,10 +1115,7 @@ struct bzamd_generators* bzamd_generators_new_device(unsigned curve_id, const vo
   auto g = std::make_unique<resident_generators>();
   g->vt = vt;
   g->n = n;
-  BZ_HIP_CHECK(hipMalloc(&g->d_addends, vt->resident_addend_size * (n + 1)));
-  vt->prepare_resident(g->d_addends, generators, n, static_cast<hipStream_t>(stream));
-  g_kernel_launches += 1;
-  BZ_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  g->table.build(*vt, generators, false, n, static_cast<hipStream_t>(stream));
   return reinterpret_cast<bzamd_generators*>(g.release());
 }
 
@@ -1135,7 +1135,7 @@ struct bzamd_generators* bzamd_generators_new_host(unsigned curve_id, const void
 void bzamd_generators_free(struct bzamd_generators* gens) {
   auto* g = reinterpret_cast<resident_generators*>(gens);
   if (g == nullptr) return;
-  if (g->d_addends != nullptr) (void)hipFree(g->d_addends);
+  g->table.release();
   delete g;
 }
 
@@ -1151,8 +1151,8 @@ void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   BZ_RELEASE_ASSERT(cc.longest <= g->n, "sequence longer than the resident generator set");
   g->vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(commitments),
-                      static_cast<u32>(g->vt->output_size), false, cc.cols, g->d_addends,
-                      static_cast<hipStream_t>(stream));
+                      static_cast<u32>(g->vt->output_size), false, cc.cols, g->table.d_addends,
+                      static_cast<hipStream_t>(stream), g->table.tables());
 }
 
 void bzamd_generator_multiples_device(unsigned curve_id, void* generators, const void* base,

@@ -8,6 +8,7 @@
 
 #include <vector>
 
+#include "blitzar_amd/csrc/api/state.h"
 #include "blitzar_amd/csrc/msm/dispatch.h"
 
 namespace bz {
@@ -18,11 +19,11 @@ struct multiexp_handle {
   std::vector<u8> host_projective; // n projective elements (host copy)
   // GPU backend: resident addends, one replica per device the backend drives (indexed by
   // device_state::slot; 16 MiB for 2^18 Grumpkin generators)
-  std::vector<void*> d_addends;
+  std::vector<resident_table> tables;
   std::vector<int> devices;
-  const void* addends_on(int device) const {
+  const resident_table* table_on(int device) const {
     for (size_t k = 0; k < devices.size(); ++k) {
-      if (devices[k] == device) return d_addends[k];
+      if (devices[k] == device) return &tables[k];
     }
     return nullptr;
   }

@@ -34,6 +34,9 @@ msm_context* msm_context_new() {
   if (const char* v = std::getenv("BLITZAR_AMD_MAX_WINDOW_BITS")) {
     msm_context_set_tuning(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)), 0, 0);
   }
+  if (const char* v = std::getenv("BLITZAR_AMD_FORCE_WINDOW_TABLES")) {
+    ctx->tuning.force_window_tables = v[0] != '0';
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_PREPARE")) ctx->overlap_prepare = v[0] != '0';
   return ctx;
 }

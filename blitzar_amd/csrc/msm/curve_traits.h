@@ -71,6 +71,11 @@ struct ed25519_msm {
   }
   // engine point -> caller generator layout (sxt_ristretto255)
   BZ_HD static void store_api_generator(u8* out, const point& p) { store_projective(out, p); }
+  // caller generator (sxt_ristretto255 = projective element_p3) -> engine point
+  BZ_HD static point point_from_api_generator(const void* api_generators, u64 i) {
+    return point_from_api_projective(api_generators, i);
+  }
+  static constexpr u32 batch_points_per_lane = 4;
   // shared inversions (Montgomery's trick over a workgroup: msm/kernels.h tree_products /
   // tree_inverses; k_prepare_addends_batched, fixed/partition_table_device.h)
   using batch_fe = fe29;
@@ -179,8 +184,15 @@ struct ed25519_niels_msm : ed25519_msm {
   }
   BZ_HD static addend batch_make_addend(const void* api_generators, u64 i, const fe29& zinv) {
     const ed_point& g = static_cast<const ed_point*>(api_generators)[i];
-    const fe29 x = f29::mul(f29::from_fe51(g.X), zinv);
-    const fe29 y = f29::mul(f29::from_fe51(g.Y), zinv);
+    return niels_of(f29::from_fe51(g.X), f29::from_fe51(g.Y), zinv);
+  }
+  // engine point and 1 / Z -> Z = 1 addend (window tables)
+  BZ_HD static addend addend_from_point(const point& p, const fe29& zinv, bool) {
+    return niels_of(p.X, p.Y, zinv);
+  }
+  BZ_HD static addend niels_of(const fe29& big_x, const fe29& big_y, const fe29& zinv) {
+    const fe29 x = f29::mul(big_x, zinv);
+    const fe29 y = f29::mul(big_y, zinv);
     ed29_niels n;
     n.YpX = f29::weak_reduce(f29::add(y, x));
     n.YmX = f29::weak_reduce(f29::sub(y, x));
@@ -276,6 +288,19 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   BZ_HD static point point_from_api_projective(const void* projective, u64 i) {
     return G29::from_point64(static_cast<const api_projective*>(projective)[i]);
   }
+  // caller generator ({X, Y, infinity} affine) -> engine point
+  BZ_HD static point point_from_api_generator(const void* api_generators, u64 i) {
+    const api_affine& g = static_cast<const api_affine*>(api_generators)[i];
+    if (g.infinity != 0) return G29::identity();
+    return {F29::from_mont64(g.X), F29::from_mont64(g.Y), F29::one()};
+  }
+  // engine point and 1 / Z -> affine addend; the identity is the all-zero addend (window tables)
+  BZ_HD static addend addend_from_point(const point& p, const batch_fe& zinv, bool is_identity) {
+    typename G29::affine a{F29::mul(p.X, zinv), F29::mul(p.Y, zinv)};
+    if (is_identity) a = {F29::zero(), F29::zero()};
+    return G29::pack(a);
+  }
+  static constexpr u32 batch_points_per_lane = G29::N <= 9 ? 4 : 2;
   BZ_HD static void store_projective(u8* out, const point& p) {
     *reinterpret_cast<api_projective*>(out) = G29::to_point64(p);
   }

@@ -56,15 +56,108 @@ __global__ void __launch_bounds__(64)
   C::store_api_generator(out + i * C::api_generator_size, acc);
 }
 
+//--------------------------------------------------------------------------------------------------
+// window tables of resident generator sets (plan.h: window_table): slice w = 2^(16 w) g_i as
+// addends, built by a chain of 16 doublings per slice on engine points and one shared-inversion
+// normalisation per slice
+//--------------------------------------------------------------------------------------------------
+template <class R>
+__global__ void __launch_bounds__(256)
+    k_load_points(typename R::point* __restrict__ points, const void* __restrict__ source, u64 n,
+                  int projective) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  points[i] = projective ? R::point_from_api_projective(source, i)
+                         : R::point_from_api_generator(source, i);
+}
+
+template <class R>
+__global__ void __launch_bounds__(256)
+    k_double_points(typename R::point* __restrict__ points, u64 n, int doublings) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  points[i] = R::dbl_n(points[i], doublings);
+}
+
+// addends[i] = the affine (Z = 1) addend of points[i]; a workgroup's points share one inversion
+// (tree_products / tree_inverses, msm/kernels.h)
+template <class R>
+__global__ void __launch_bounds__(256)
+    k_points_to_addends(typename R::addend* __restrict__ addends,
+                        const typename R::point* __restrict__ points, u64 n) {
+  using fe = typename R::batch_fe;
+  constexpr u32 K = R::batch_points_per_lane;
+  __shared__ fe tree[512];
+  const u32 tid = threadIdx.x;
+  const u64 base = static_cast<u64>(blockIdx.x) * 256 * K;
+  fe z[K], prefix[K];
+  bool is_identity[K];
+  static_for<K>([&](auto jc) {
+    constexpr u32 j = decltype(jc)::value;
+    const u64 i = base + static_cast<u64>(j) * 256 + tid;
+    is_identity[j] = false;
+    z[j] = i < n ? R::batch_z(points[i], is_identity[j]) : R::batch_one();
+    if constexpr (j == 0) {
+      prefix[0] = z[0];
+    } else {
+      prefix[j] = R::batch_mul(prefix[j - 1], z[j]);
+    }
+  });
+  tree[256 + tid] = prefix[K - 1];
+  tree_products<R, 256>(tree, tid);
+  if (tid < 64) {
+    const fe inv = R::batch_wave_invert(tree[1]);
+    if (tid == 0) tree[1] = inv;
+  }
+  tree_inverses<R, 256>(tree, tid);
+  fe inv = tree[256 + tid];
+  static_for<K>([&](auto jc) {
+    constexpr u32 j = K - 1 - decltype(jc)::value;
+    fe zinv = inv;
+    if constexpr (j != 0) {
+      zinv = R::batch_mul(inv, prefix[j - 1]);
+      inv = R::batch_mul(inv, z[j]);
+    }
+    const u64 i = base + static_cast<u64>(j) * 256 + tid;
+    if (i < n) addends[i] = R::addend_from_point(points[i], zinv, is_identity[j]);
+  });
+}
+
 // R = the trait used against resident generator sets, H = the trait of the host backend (both C
 // itself, except curve25519: the host backend keeps the projective cached addends -- one inversion
 // per generator is only worth it where the inversions are batched on the device)
 template <class C, class R = C, class H = C> struct curve_tu {
   static void msm_resident(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                            const std::vector<host_column>& cols, const void* d_addends,
-                           hipStream_t stream) {
+                           hipStream_t stream, const window_table* tables) {
     msm_enqueue<R>(ctx, d_out, out_stride, projective_out, cols,
-                   static_cast<const typename R::addend*>(d_addends), nullptr, stream);
+                   static_cast<const typename R::addend*>(d_addends), nullptr, stream, tables);
+  }
+  // slices 0 .. windows-1 of a resident set: d_table[w * stride + i] = addend of 2^(16 w) g_i
+  // (blocking: scratch for the chain of points is allocated and freed here)
+  static void build_window_table(void* d_table, const void* d_source, bool source_projective,
+                                 u64 n, u64 stride, u32 windows, hipStream_t stream) {
+    if (n == 0) return;
+    using point = typename R::point;
+    point* d_points = nullptr;
+    BZ_HIP_CHECK(hipMalloc(&d_points, sizeof(point) * n));
+    const u32 blocks = ceil_div_u32(n, 256);
+    hipLaunchKernelGGL((k_load_points<R>), dim3(blocks), dim3(256), 0, stream, d_points, d_source,
+                       n, source_projective ? 1 : 0);
+    auto* table = static_cast<typename R::addend*>(d_table);
+    for (u32 w = 0; w < windows; ++w) {
+      if (w != 0) {
+        hipLaunchKernelGGL((k_double_points<R>), dim3(blocks), dim3(256), 0, stream, d_points, n,
+                           16);
+      }
+      hipLaunchKernelGGL((k_points_to_addends<R>),
+                         dim3(ceil_div_u32(n, 256ull * R::batch_points_per_lane)), dim3(256), 0,
+                         stream, table + static_cast<u64>(w) * stride, d_points, n);
+    }
+    BZ_HIP_CHECK(hipGetLastError());
+    g_kernel_launches += 1 + 2 * windows;
+    BZ_HIP_CHECK(hipStreamSynchronize(stream));
+    BZ_HIP_CHECK(hipFree(d_points));
   }
   static void prepare_resident(void* d_addends, const void* d_api_generators, u64 n,
                                hipStream_t stream) {
@@ -163,6 +256,7 @@ template <class C, class R = C, class H = C> struct curve_tu {
                                  &curve_tu::msm_resident,
                                  &curve_tu::prepare_resident,
                                  &curve_tu::prepare_resident_projective,
+                                 &curve_tu::build_window_table,
                                  sizeof(typename compact_ops<H>::compact),
                                  &write_partition_table<H>,
                                  &write_partition_table_device<H>,

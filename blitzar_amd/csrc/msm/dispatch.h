@@ -44,13 +44,18 @@ struct curve_vtable {
   // resident generator sets (registered once, reused by many calls): their own addend layout
   // (curve25519: Z = 1, 128 bytes; the Weierstrass curves: the same affine addends)
   size_t resident_addend_size;
+  // `tables`: d_addends is slice 0 of a window table (plan.h), or nullptr
   void (*msm_resident)(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const std::vector<host_column>& cols, const void* d_addends,
-                       hipStream_t stream);
+                       hipStream_t stream, const window_table* tables);
   void (*prepare_resident)(void* d_addends, const void* d_api_generators, u64 n,
                            hipStream_t stream);
   void (*prepare_resident_projective)(void* d_addends, const void* d_projective, u64 n,
                                       hipStream_t stream);
+  // window table of a resident set: d_table[w * stride + i] = addend of 2^(16 w) g_i for
+  // w < windows, from C-ABI generators or projective elements on the device (blocking)
+  void (*build_window_table)(void* d_table, const void* d_source, bool source_projective, u64 n,
+                             u64 stride, u32 windows, hipStream_t stream);
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
   bool (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);

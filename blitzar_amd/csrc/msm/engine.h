@@ -180,10 +180,12 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
 // (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
 // Columns are processed in batches bounded by the launch grid (tasks per batch) and by
 // `msm_tuning::max_workspace_bytes`; batches reuse the same arena back to back on the stream.
+// `tables`: `d_addends` is slice 0 of a window table (plan.h) whose further slices follow it.
 template <class C>
 void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                  const std::vector<host_column>& cols, const typename C::addend* d_addends,
-                 const void* d_api_generators, hipStream_t stream) {
+                 const void* d_api_generators, hipStream_t stream,
+                 const window_table* tables = nullptr) {
   if (cols.empty()) return;
   std::lock_guard<std::mutex> lock(ctx.mu);
   configure_sort_kernels(ctx);
@@ -193,6 +195,11 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   for (const auto& c : cols) any_signed = any_signed || c.is_signed;
   // Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.
   if (any_signed && tune.max_window_bits > 15) tune.max_window_bits = 15;
+  if (tables != nullptr) {
+    const double table_bytes = static_cast<double>(sizeof(typename C::addend)) *
+                               static_cast<double>(tables->stride) * tables->windows;
+    tune.table_penalty = table_bytes > 200.0 * (1 << 20) ? 1.15 : 1.03;
+  }
 
   // cut the columns into batches: the longest prefix of the remaining columns whose plan respects
   // the launch-grid and workspace limits (a single column is always accepted); found by bisection,
@@ -202,7 +209,8 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   size_t need = 0;
   const bool needs_addends = d_addends == nullptr;
   auto plan_range = [&](size_t begin, size_t end, size_t& bytes) {
-    msm_plan p = make_msm_plan(std::vector<host_column>(cols.begin() + begin, cols.begin() + end), tune);
+    msm_plan p = make_msm_plan(std::vector<host_column>(cols.begin() + begin, cols.begin() + end),
+                               tune, tables);
     bytes = msm_workspace_bytes<C>(p, needs_addends, partial_stride_of(p));
     return p;
   };
@@ -348,7 +356,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.horner_state = ctx.arena.take<point>(num_cols);
   const size_t part_lds = sizeof(u32) * plan.max_task_groups;
   const u32 seg_blocks =
-      ceil_div_u32(plan.max_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
+      ceil_div_u32(plan.max_task_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
 
   // One stream, stages in order.  (Running the sort of window group k+1 and the reduce / Horner of
   // group k-1 on side streams under the accumulation of group k was measured on MI355X and is
@@ -360,13 +368,14 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // 1.74 -> 1.87 ms.)
   ctx.timer.timed(timing, 1, stream, [&] {
     if (d_ranges != nullptr) {
-      hipLaunchKernelGGL(k_recode_packed, dim3(ceil_div_u32(plan.max_rows, kPackedTileRows)),
+      hipLaunchKernelGGL(k_recode_packed,
+                         dim3(ceil_div_u32(plan.max_recode_rows, kPackedTileRows)),
                          dim3(kPackedRecodeThreads), kPackedTileBytes, stream, b.digits, b.cols,
                          b.tasks, d_ranges, static_cast<u32>(ranges.size()),
-                         plan.columns[0].row_stride, plan.max_rows);
+                         plan.columns[0].row_stride, plan.max_recode_rows, plan.max_rows);
       return;
     }
-    const u32 chunks = ceil_div_u32(plan.max_rows, 256);
+    const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
     const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
     const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
     hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, stream, b.digits, b.cols,

@@ -185,6 +185,24 @@ static __global__ void __launch_bounds__(256)
     const column_desc col = columns[rest % num_columns];
     const u64 chunk = (rest / num_columns) * 8 + xcd;
     const u64 row = chunk * blockDim.x + threadIdx.x;
+    if (col.merged_stride != 0) {
+      // window tables: the column's windows are slices of one task, virtual row = window *
+      // stride + row; rows between the column's end and the slice's are zero digits
+      if (row >= col.merged_stride) continue;
+      i16* dst = digits + tasks[col.first_task].entry_base + row;
+      digit_recoder rec;
+      if (row < col.n) {
+        rec.init(col.data + row * col.row_stride, col.bit_offset, col.bit_width, false,
+                 col.window_bits);
+      }
+      for (u32 wi = 0; wi < col.num_windows; ++wi) {
+        const int d = row < col.n ? rec.next() : 0;
+        if (wi + 1 < col.num_windows || row < col.n) {
+          dst[static_cast<u64>(wi) * col.merged_stride] = static_cast<i16>(-d);
+        }
+      }
+      continue;
+    }
     if (row >= col.n) continue;
     digit_recoder rec;
     rec.init(col.data + row * col.row_stride, col.bit_offset, col.bit_width, col.is_signed != 0,
@@ -206,7 +224,7 @@ static __global__ void __launch_bounds__(256)
 static __global__ void __launch_bounds__(kPackedRecodeThreads)
     k_recode_packed(i16* __restrict__ digits, const column_desc* __restrict__ columns,
                     const task_desc* __restrict__ tasks, const recode_range* __restrict__ ranges,
-                    u32 num_ranges, u64 row_stride, u64 max_rows) {
+                    u32 num_ranges, u64 row_stride, u64 max_rows, u64 data_rows) {
   extern __shared__ __attribute__((aligned(16))) u8 tile[];
   __shared__ u32 row_shift[kPackedTileRows];
   const u64 row0 = static_cast<u64>(blockIdx.x) * kPackedTileRows;
@@ -220,6 +238,8 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
     const u32 chunks = (range.span + 15 + 15) / 16;
     for (u32 idx = tid; idx < rows * chunks; idx += kPackedRecodeThreads) {
       const u32 r = idx / chunks, k = idx % chunks;
+      // rows past the caller's data (zero-digit filler of window-table slices) are never read
+      if (row0 + r >= data_rows) continue;
       const uintptr_t start = reinterpret_cast<uintptr_t>(range.base) + (row0 + r) * row_stride;
       const uintptr_t aligned = start & ~static_cast<uintptr_t>(15);
       const uintptr_t lo = aligned + 16 * k; // this chunk covers [lo, lo + 16)
@@ -239,6 +259,13 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
     for (u32 c = wave; c < range.num_columns; c += kPackedRecodeThreads / 64) {
       const column_desc col = columns[range.first_column + c];
       const u64 row = row0 + lane;
+      if (col.merged_stride != 0 && lane < rows && row >= col.n && row < col.merged_stride) {
+        // window tables: zero digits between the column's end and the slice's
+        i16* dst = digits + tasks[col.first_task].entry_base + row;
+        for (u32 wi = 0; wi + 1 < col.num_windows; ++wi) {
+          dst[static_cast<u64>(wi) * col.merged_stride] = 0;
+        }
+      }
       if (lane < rows && row < col.n) {
         // ten aligned words from the tile cover the <= 33 bytes of the field
         const u32 at = lane * kPackedTilePitch + row_shift[lane] +
@@ -252,7 +279,11 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
                          col.window_bits);
         for (u32 wi = 0; wi < col.num_windows; ++wi) {
           const int d = rec.next();
-          digits[tasks[col.first_task + wi].entry_base + row] = static_cast<i16>(-d);
+          const u64 at = col.merged_stride != 0
+                             ? tasks[col.first_task].entry_base +
+                                   static_cast<u64>(wi) * col.merged_stride + row
+                             : tasks[col.first_task + wi].entry_base + row;
+          digits[at] = static_cast<i16>(-d);
         }
       }
     }
@@ -1188,7 +1219,8 @@ __global__ void __launch_bounds__(kCombineThreads)
   const column_desc col = columns[blockIdx.x];
   const u32 tid = threadIdx.x;
   u8* dst = out + static_cast<u64>(blockIdx.x) * out_stride;
-  u32 w_hi = w_hi_arg < col.num_windows ? w_hi_arg : col.num_windows;
+  // windows = the column's tasks (ONE for a column on window tables: no chain at all)
+  u32 w_hi = w_hi_arg < col.num_tasks ? w_hi_arg : col.num_tasks;
   const u32 w_lo = w_lo_arg < w_hi ? w_lo_arg : w_hi;
   if (first) {
     // windows above the highest populated one contribute nothing: start the chain below them

@@ -35,7 +35,10 @@ constexpr u32 kMaxGroupBits = 10;         // 2^s counters of the per-group sort 
 constexpr u32 kMaxGroupsLog2 = 10;        // pass 1 writes one stream per group: keep them few
 
 // buckets a reduce block covers (threads per block x buckets per thread), shared with kernels.h
-constexpr u32 kReduceThreads = 256;
+#ifndef BZ_REDUCE_THREADS
+#define BZ_REDUCE_THREADS 256
+#endif
+constexpr u32 kReduceThreads = BZ_REDUCE_THREADS;
 #ifndef BZ_REDUCE_SEGMENT_LOG2
 #define BZ_REDUCE_SEGMENT_LOG2 3
 #endif
@@ -69,8 +72,24 @@ struct column_desc {
   u32 bit_width;   // 1..256; a byte-aligned column has bit_offset 0, width 8 * nbytes
   u32 is_signed;   // two's complement over bit_width bits
   u32 window_bits; // c
-  u32 num_windows; // W
+  u32 num_windows; // W: digits per scalar
   u32 first_task;  // task index of window 0; task = first + window
+  // window tables (resident generator sets with 2^(c w) g_i precomputed, see window_table below):
+  // all W windows of the column share ONE task whose "rows" are (window, row) pairs,
+  // virtual row = window * merged_stride + row; 0 = one task per window
+  u32 num_tasks;     // tasks of the column: W, or 1 when merged
+  u32 merged_stride; // rows of one table slice, or 0
+};
+
+// Precomputed multiples of a resident generator set: slice w holds 2^(bits w) g_i, `stride` rows
+// per slice (>= the number of generators, multiple of 8), slices back to back -- so a sorted
+// entry's virtual row IS its row in the table and k_accumulate needs no change.  With every window
+// accumulating into the same 2^(bits-1) buckets, a column costs one bucket reduction instead of W
+// and its Horner chain over windows disappears.
+struct window_table {
+  u64 stride = 0;
+  u32 windows = 0; // slices available
+  u32 bits = 16;   // window width the slices were built for
 };
 
 struct msm_plan {
@@ -81,6 +100,8 @@ struct msm_plan {
   u64 total_groups = 0;    // entries of all group tables (group_start, group_cursor)
   u64 total_segments = 0;
   u64 max_rows = 0;        // longest column
+  u64 max_task_rows = 0;   // most (virtual) rows of a task: k_accumulate's grid
+  u64 max_recode_rows = 0; // rows k_recode visits per column (merged columns: the table stride)
   u32 max_task_buckets = 0;
   u32 max_task_slices = 0;
   u32 max_task_groups = 0;
@@ -98,6 +119,11 @@ struct msm_tuning {
   // window-width cost model: from this many columns on, buckets cost `throughput_bucket_cost`
   size_t throughput_columns = 4;
   double throughput_bucket_cost = 12.0;
+  // window tables: gathers from a table beyond the 256 MiB Infinity Cache cost this much more per
+  // addition (measured on MI355X: 51 against 43 ps with a 2 GiB curve25519 table); a table that
+  // fits costs `table_penalty_cached`.  `force_window_tables` (tests) merges whenever possible.
+  double table_penalty = 1.0;
+  bool force_window_tables = false;
 };
 
 inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b); }
@@ -175,7 +201,27 @@ inline partition_geometry choose_partition(u64 n, u32 window_bits,
   return g;
 }
 
-inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tuning& tune = {}) {
+// a column uses the window tables when it fills at least half a slice (the rest of the slice is
+// recoded as zero digits), has more than one window and is unsigned (signed columns store -D and
+// stay at c <= 15)
+inline bool use_window_table(const host_column& hc, const window_table* tables,
+                             const msm_tuning& tune, double bucket_cost) {
+  if (tables == nullptr || tables->windows == 0 || hc.is_signed || hc.n == 0) return false;
+  if (hc.n > tables->stride || 2 * hc.n < tables->stride) return false;
+  const u32 w = ceil_div_u32(hc.bit_width + 1, tables->bits);
+  if (w <= 1 || w > tables->windows) return false;
+  if (tune.force_window_tables) return true;
+  // same cost model as choose_window_bits: one bucket set for all windows, dearer gathers
+  const u32 c = choose_window_bits(hc.n, hc.bit_width, tune, bucket_cost);
+  const double separate = static_cast<double>(ceil_div_u32(hc.bit_width + 1, c)) *
+                          (static_cast<double>(hc.n) + bucket_cost * static_cast<double>(1u << (c - 1)));
+  const double merged = static_cast<double>(w) * static_cast<double>(hc.n) * tune.table_penalty +
+                        bucket_cost * static_cast<double>(1u << (tables->bits - 1));
+  return merged < separate;
+}
+
+inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tuning& tune = {},
+                              const window_table* tables = nullptr) {
   msm_plan plan;
   plan.columns.reserve(cols.size());
   size_t nonempty = 0;
@@ -198,19 +244,24 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       continue;
     }
     const u32 bits = hc.bit_width;
-    const u32 c = choose_window_bits(hc.n, bits, tune, bucket_cost);
+    const bool merged = use_window_table(hc, tables, tune, bucket_cost);
+    const u32 c = merged ? tables->bits : choose_window_bits(hc.n, bits, tune, bucket_cost);
     const u32 w = ceil_div_u32(bits + 1, c);
     const u32 buckets = 1u << (c - 1);
+    // rows of a task: the column's, or every (window, row) pair up to the last window's rows
+    const u64 task_rows = merged ? static_cast<u64>(w - 1) * tables->stride + hc.n : hc.n;
     const partition_geometry geo =
-        choose_partition(hc.n, c, tune.partition_group_entries);
+        choose_partition(task_rows, c, tune.partition_group_entries);
     const u32 slices = geo.num_slices;
     cd.window_bits = c;
     cd.num_windows = w;
-    for (u32 wi = 0; wi < w; ++wi) {
+    cd.num_tasks = merged ? 1 : w;
+    cd.merged_stride = merged ? static_cast<u32>(tables->stride) : 0;
+    for (u32 wi = 0; wi < cd.num_tasks; ++wi) {
       task_desc t{};
       t.column = static_cast<u32>(ci);
       t.window = wi;
-      t.rows = hc.n;
+      t.rows = task_rows;
       t.num_buckets = buckets;
       t.num_slices = slices;
       t.slice_rows = geo.slice_rows;
@@ -222,11 +273,14 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       t.segment_base = plan.total_segments;
       plan.total_buckets += buckets;
       // keep every task's entry range 16-byte aligned for both the i16 and the u32 views
-      plan.total_entries += (hc.n + 7) & ~7ull;
+      plan.total_entries += (task_rows + 7) & ~7ull;
       plan.total_groups += geo.num_groups + 1;
-      plan.total_segments += (hc.n + kSegmentEntries - 1) / kSegmentEntries;
+      plan.total_segments += (task_rows + kSegmentEntries - 1) / kSegmentEntries;
       plan.tasks.push_back(t);
     }
+    if (task_rows > plan.max_task_rows) plan.max_task_rows = task_rows;
+    const u64 recode_rows = merged ? tables->stride : hc.n;
+    if (recode_rows > plan.max_recode_rows) plan.max_recode_rows = recode_rows;
     if (buckets > plan.max_task_buckets) plan.max_task_buckets = buckets;
     if (slices > plan.max_task_slices) plan.max_task_slices = slices;
     if (geo.num_groups > plan.max_task_groups) plan.max_task_groups = geo.num_groups;
