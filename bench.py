@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0
 # integer-ALU side of k_accumulate (the honest binding bound).  v_mad_u64_u32 per
 # bucket addition = the count in the kernel's ISA (field products x 92: 81 limb products, 9
 # wrap-arounds, 2 folds).  Peak: the instruction issues once per 4 shader cycles per SIMD
-# (profiles/round2_valu_rates.md: twice the 2 cycles of a plain VALU op), 1024 SIMDs; the clock is
+# (profiles/round2_valu_rates.txt: 4.5 against the 2.4 of a plain VALU op), 1024 SIMDs; the clock is
 # the effective shader clock the same micro-benchmark measures under an all-SIMD integer load.
 MADS_PER_ADDITION = {"cached": 736, "niels": 644}
 SIMDS = 1024

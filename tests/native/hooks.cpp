@@ -199,6 +199,41 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
   totals[5] = plan.total_groups;
 }
 
+// planner with a window table (msm/plan.h `window_table`): per column {window_bits, num_windows,
+// num_tasks, merged_stride, rows of the column's first task (low / high 32 bits)}; totals {tasks,
+// total_buckets, total_entries, max_task_rows, max_recode_rows, max_rows}
+void bz_plan_tables(u32* per_column, u64* totals, const u64* n, const u32* bit_width,
+                    const int* is_signed, u32 num_columns, u64 stride, u32 windows, int force,
+                    double table_penalty) {
+  std::vector<host_column> cols(num_columns);
+  for (u32 i = 0; i < num_columns; ++i) {
+    cols[i] = host_column{nullptr, n[i], (bit_width[i] + 7) / 8, 0, bit_width[i], is_signed[i] != 0};
+  }
+  msm_tuning tune;
+  tune.force_window_tables = force != 0;
+  tune.table_penalty = table_penalty;
+  window_table tables;
+  tables.stride = stride;
+  tables.windows = windows;
+  msm_plan plan = make_msm_plan(cols, tune, &tables);
+  for (u32 i = 0; i < num_columns; ++i) {
+    const column_desc& c = plan.columns[i];
+    const u64 rows = c.num_tasks == 0 ? 0 : plan.tasks[c.first_task].rows;
+    per_column[6 * i + 0] = c.window_bits;
+    per_column[6 * i + 1] = c.num_windows;
+    per_column[6 * i + 2] = c.num_tasks;
+    per_column[6 * i + 3] = c.merged_stride;
+    per_column[6 * i + 4] = static_cast<u32>(rows);
+    per_column[6 * i + 5] = static_cast<u32>(rows >> 32);
+  }
+  totals[0] = plan.tasks.size();
+  totals[1] = plan.total_buckets;
+  totals[2] = plan.total_entries;
+  totals[3] = plan.max_task_rows;
+  totals[4] = plan.max_recode_rows;
+  totals[5] = plan.max_rows;
+}
+
 // column ranges of k_recode_packed (msm/plan.h): columns = bit fields at byte offsets `offset[i]`
 // of rows `stride[i]` bytes apart; out = {first_column, num_columns, base offset, span} per range;
 // returns the number of ranges (0: not a packed batch)

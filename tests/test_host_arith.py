@@ -440,3 +440,33 @@ def test_batched_inversion_tree_model():
                 i = j * T + t
                 if i < n:
                     assert zinv * zs[i] % p == 1
+
+
+def test_planner_window_tables():
+    """msm/plan.h with a window table of 17 slices, `stride` rows apart: a column merges into ONE
+    task of (windows - 1) * stride + n virtual rows when it is unsigned, fills at least half a
+    slice, has more than one window and the cost model agrees (or merging is forced)"""
+    stride = 1 << 18
+    ns = [stride, stride - 100, stride, stride, stride // 4, 0, stride]
+    widths = [256, 252, 8, 128, 256, 32, 32]
+    signed = [0, 0, 0, 1, 0, 0, 0]
+    per, totals = hooks.plan_tables(ns, widths, signed, stride, 17, force=True)
+    # 256-bit: 17 windows of 16 bits in one task
+    assert per[0].tolist()[:4] == [16, 17, 1, stride]
+    assert int(per[0][4]) + (int(per[0][5]) << 32) == 16 * stride + ns[0]
+    # 252-bit, ragged: 16 windows, rows up to the last window's end
+    assert per[1].tolist()[:4] == [16, 16, 1, stride]
+    assert int(per[1][4]) == 15 * stride + ns[1]
+    assert per[2][2] == per[2][1] and per[2][3] == 0        # one window: nothing to merge
+    assert per[3][3] == 0 and per[3][2] == per[3][1]        # signed: separate windows
+    assert per[4][3] == 0                                   # short column: separate windows
+    assert per[5].tolist()[:4] == [1, 0, 0, 0]              # empty column
+    assert per[6].tolist()[:4] == [16, 3, 1, stride]        # 32-bit: 3 windows merged
+    assert int(totals[3]) == 16 * stride + stride           # k_accumulate's grid: virtual rows
+    assert int(totals[4]) == stride and int(totals[5]) == stride
+    # the cost model: many long 256-bit columns merge (one bucket reduction instead of ~20, and
+    # c = 16 becomes affordable); a single column does not when the table misses the cache
+    many, _ = hooks.plan_tables([stride] * 8, [256] * 8, [0] * 8, stride, 17, table_penalty=1.03)
+    assert all(row[2] == 1 and row[0] == 16 for row in many.tolist())
+    one, _ = hooks.plan_tables([1 << 20], [252], [0], 1 << 20, 17, table_penalty=1.15)
+    assert one[0][2] == one[0][1] == 16 and one[0][3] == 0
