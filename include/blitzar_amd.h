@@ -8,6 +8,12 @@
  *
  * All pointers marked DEVICE must be valid on the current HIP device.  `stream` is a hipStream_t
  * passed as void* (NULL = the default stream).  Calls are asynchronous unless stated otherwise.
+ *
+ * Concurrency: the engine keeps one workspace per device.  Calls on one device are executed in the
+ * order they were enqueued, whatever streams they arrive on (a call on another stream first waits
+ * for the previous call's last kernel; they could not overlap usefully anyway, k_accumulate fills
+ * the machine), and the host side of every call takes the device context's lock, so several host
+ * threads may enqueue.  The blocking sxt_* entry points serialise on one process-wide lock.
  */
 #ifndef BLITZAR_AMD_BLITZAR_AMD_H
 #define BLITZAR_AMD_BLITZAR_AMD_H
