@@ -38,12 +38,15 @@ BZ_HD fe29 zero() { return {{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
 BZ_HD fe29 one() { return {{1, 0, 0, 0, 0, 0, 0, 0, 0}}; }
 
 // a * b + c in one v_mad_u64_u32.  BZ_F29_MAD_MODE=1 passes the result through an empty asm
-// statement so that hipcc cannot reassociate the column sums (it restarts every column from 0 and
-// joins the carry with an extra 64-bit add); measured on MI355X (tools/ubench/fmul_rates.hip) the
-// reassociated form is ~4 % faster for a whole point addition at 4-8 waves per SIMD and 20 % faster
-// for a lone wave (more ILP), so mode 0 is the default.
+// statement so that hipcc cannot reassociate the column sums (left alone it restarts every column
+// from 0 and joins the carry with an extra 64-bit add, ~4 cycles each, 112 per point addition;
+// pinned, it pads the dependent mads with s_nop instead, which other waves fill).  Measured inside
+// the real kernels on MI355X (A/B on one box, profiles/round2_ab_mad_mode.log): k_accumulate 0.723 ->
+// 0.688 ms at 3 waves per SIMD, the lone-wave kernels mixed (k_reduce 0.203 -> 0.209, k_horner
+// 0.204 -> 0.197): config 2 1.404 -> 1.364 ms, so mode 1 is the default.  (A micro-benchmark of a
+// dependent chain of additions, tools/ubench/fmul_rates.hip, had favoured mode 0.)
 #ifndef BZ_F29_MAD_MODE
-#define BZ_F29_MAD_MODE 0
+#define BZ_F29_MAD_MODE 1
 #endif
 BZ_HD u64 mad(u32 a, u32 b, u64 c) {
   u64 d = static_cast<u64>(a) * b + c;

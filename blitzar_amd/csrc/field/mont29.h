@@ -32,6 +32,10 @@
 
 #include "blitzar_amd/csrc/field/mont29_params.h"
 
+#ifndef BZ_MONT29_MAD_MODE
+#define BZ_MONT29_MAD_MODE 0
+#endif
+
 #if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
 #include <cstdio>
 #include <cstdlib>
@@ -130,7 +134,16 @@ template <class P> struct mont29 {
     return h;
   }
 
-  BZ_HD static u64 mad(u32 a, u32 b, u64 c) { return static_cast<u64>(a) * b + c; }
+  // a * b + c in one v_mad_u64_u32; BZ_MONT29_MAD_MODE=1 pins the accumulation order (see
+  // field/f29.h BZ_F29_MAD_MODE: hipcc otherwise splits the column sums and joins them with extra
+  // 64-bit adds)
+  BZ_HD static u64 mad(u32 a, u32 b, u64 c) {
+    u64 d = static_cast<u64>(a) * b + c;
+#if defined(__HIP_DEVICE_COMPILE__) && BZ_MONT29_MAD_MODE == 1
+    asm("" : "+v"(d));
+#endif
+    return d;
+  }
 
 #if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
   static void check_mul_operands(const fe& a, const fe& b) {
