@@ -73,6 +73,25 @@ template <class P> struct sw29 {
   // tail shared by Alg. 7 and 8.  In: t0 = 3 X1X2 (B 3, V < 3.7), t1 = Y1Y2 (V < 1.3),
   // u2 = |3b| Z1Z2 (V < 4), t3 = X1Y2 + X2Y1 (B 1, V < 5.9), t4 = Y1Z2 + Y2Z1 (B <= 2, V < 7.1),
   // u3 = |3b| (X1Z2 + X2Z1) (V < 4).
+  // Fast: the pinned product-scanning products of field/mont29.h (k_accumulate)
+  template <bool Fast>
+  BZ_HD static fe prod(const fe& a, const fe& b) {
+    if constexpr (Fast) {
+      return F::mul_pinned(a, b);
+    } else {
+      return F::mul(a, b);
+    }
+  }
+  template <bool Fast>
+  BZ_HD static fe prod2(const fe& a, const fe& b, const fe& c, const fe& d) {
+    if constexpr (Fast) {
+      return F::mul2_pinned(a, b, c, d);
+    } else {
+      return F::mul2(a, b, c, d);
+    }
+  }
+
+  template <bool Fast = false>
   BZ_HD static point finish(const fe& t0, const fe& t1, const fe& u2, const fe& t3, const fe& t4,
                             const fe& u3) {
     const pm s = plus_minus(t1, u2);
@@ -83,33 +102,34 @@ template <class P> struct sw29 {
       const fe z3 = F::norm(s.plus);                              // B 1, V < 5.3
       const fe& t1m = s.minus;                                    // B 1, V < 9.3
       const fe t4n = F::template neg<8>(t4);                      // B <= 3, V < 8
-      r.X = F::mul2(t3, t1m, t4n, u3);                            // B 1*1 + 3*1, V 55 + 32
-      r.Y = F::mul2(t1m, z3, u3, t0);                             // B 1*1 + 1*3
-      r.Z = F::mul2(z3, t4, t0, t3);                              // B 1*2 + 3*1
+      r.X = prod2<Fast>(t3, t1m, t4n, u3);                            // B 1*1 + 3*1, V 55 + 32
+      r.Y = prod2<Fast>(t1m, z3, u3, t0);                             // B 1*1 + 1*3
+      r.Z = prod2<Fast>(z3, t4, t0, t3);                              // B 1*2 + 3*1
     } else {
       // 3b = -|3b|: z3 = t1 - u2, t1' = t1 + u2, y3 = -u3
       const fe& z3 = s.minus;                                     // B 1, V < 9.3
       const fe& t1m = s.plus;                                     // B 2, V < 5.3
       const fe t0r = F::norm(t0);                                 // B 1, V < 3.7
       const fe t0n = F::template neg<4>(t0r);                     // B <= 3, V < 4
-      r.X = F::mul2(t3, t1m, t4, u3);                             // B 1*2 + 2*1
-      r.Y = F::mul2(t1m, z3, u3, t0n);                            // B 2*1 + 1*3
-      r.Z = F::mul2(z3, t4, t0r, t3);                             // B 1*2 + 1*1
+      r.X = prod2<Fast>(t3, t1m, t4, u3);                             // B 1*2 + 2*1
+      r.Y = prod2<Fast>(t1m, z3, u3, t0n);                            // B 2*1 + 1*3
+      r.Z = prod2<Fast>(z3, t4, t0r, t3);                             // B 1*2 + 1*1
     }
     return r;
   }
 
   // p + q (q negated when `negate`), Alg. 8; q must not be the identity
+  template <bool Fast = false>
   BZ_HD static point add_mixed(const point& p, const affine& q, bool negate) {
     const fe y2 = F::select(q.y, F::norm(F::template neg<2>(q.y)), negate); // V <= 2
-    fe t0 = F::mul(p.X, q.x);                                                // V < 1.1
-    const fe t1 = F::mul(p.Y, y2);                                           // V < 1.1
-    fe t3 = F::mul(F::add(q.x, y2), F::add(p.X, p.Y));                       // B 2*2, V 3*12 -> < 1.3
+    fe t0 = prod<Fast>(p.X, q.x);                                            // V < 1.1
+    const fe t1 = prod<Fast>(p.Y, y2);                                       // V < 1.1
+    fe t3 = prod<Fast>(F::add(q.x, y2), F::add(p.X, p.Y));                   // B 2*2, V 3*12 -> < 1.3
     t3 = F::norm(F::template sub<4>(t3, F::add(t0, t1)));                    // V < 5.3
-    const fe t4 = F::add(F::mul(y2, p.Z), p.Y);                              // B 2, V < 7.1
-    const fe y3 = F::add(F::mul(q.x, p.Z), p.X);                             // B 2, V < 7.1
+    const fe t4 = F::add(prod<Fast>(y2, p.Z), p.Y);                          // B 2, V < 7.1
+    const fe y3 = F::add(prod<Fast>(q.x, p.Z), p.X);                         // B 2, V < 7.1
     t0 = F::add(F::add(t0, t0), t0);                                         // B 3, V < 3.3
-    return finish(t0, t1, mul_b3(p.Z), t3, t4, mul_b3(y3));
+    return finish<Fast>(t0, t1, mul_b3(p.Z), t3, t4, mul_b3(y3));
   }
 
   // p + q, Alg. 7

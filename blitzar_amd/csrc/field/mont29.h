@@ -246,6 +246,66 @@ template <class P> struct mont29 {
     return h;
   }
 
+  // The same products by PRODUCT scanning: one 64-bit accumulator walks the 2N - 1 columns, the
+  // carry into the next column rides in the accumulator (no per-row carry join, no final carry
+  // sweep: ~17 fewer 64-bit operations per product than the operand-scanning form above), the
+  // quotient digit m_k is fixed when column k is complete.  The accumulation order is pinned
+  // (an empty asm on every step) -- hipcc would otherwise split each column into independent
+  // partial sums and join them again.  Same operand contract, bit-identical results.  A single
+  // dependent chain: for kernels with several waves per SIMD (k_accumulate); a lone wave is
+  // better served by the N independent accumulators of `mul`.
+  BZ_HD static u64 mad_pinned(u32 a, u32 b, u64 c) {
+    u64 d = static_cast<u64>(a) * b + c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(d));
+#endif
+    return d;
+  }
+
+  template <bool Two>
+  BZ_HD static fe mul_scan(const fe& a, const fe& b, const fe& c, const fe& d) {
+#if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Two) {
+      check_mul2_operands(a, b, c, d);
+    } else {
+      check_mul_operands(a, b);
+    }
+#endif
+    u32 m[N];
+    fe h;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; ++k) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int j = k - i;
+        if (j < 0 || j >= N) continue;
+        acc = mad_pinned(a.v[i], b.v[j], acc);
+        if constexpr (Two) acc = mad_pinned(c.v[i], d.v[j], acc);
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int j = k - i;
+        if (j < 0 || j >= N || i >= k) continue; // m_i exists for i < k (m_k joins below)
+        acc = mad_pinned(m[i], P::p(j), acc);
+      }
+      if (k < N) {
+        m[k] = (static_cast<u32>(acc) * P::inv) & kMask;
+        acc = mad_pinned(m[k], P::p(0), acc); // the column's low LB bits are now zero
+      } else {
+        h.v[k - N] = static_cast<u32>(acc) & kMask;
+      }
+      acc >>= LB;
+    }
+    BZ_M29_ASSERT(acc < (u64{1} << LB), "mul_scan: result does not fit (V products too large)");
+    h.v[N - 1] = static_cast<u32>(acc);
+    return h;
+  }
+  BZ_HD static fe mul_pinned(const fe& a, const fe& b) { return mul_scan<false>(a, b, a, b); }
+  BZ_HD static fe mul2_pinned(const fe& a, const fe& b, const fe& c, const fe& d) {
+    return mul_scan<true>(a, b, c, d);
+  }
+
   // a * c for a small constant c, normalised (V grows by the factor c)
   BZ_HD static fe mul_small(const fe& a, u32 c) {
     fe h;

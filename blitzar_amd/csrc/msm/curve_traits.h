@@ -217,6 +217,15 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr size_t api_generator_size = sizeof(api_affine);
   static constexpr size_t projective_size = sizeof(api_projective);
   static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
+  // k_accumulate's additions use the pinned product-scanning field products (field/mont29.h) on the
+  // 9-limb curves: config 4 accumulate 348.3 -> 338.8 ms, config 5 138.1 -> 135.1 (A/B on one box,
+  // profiles/round2_ab_pinned_products.log).  With 14 limbs the quotient digits and the single
+  // chain spill (bls12-381: 11.3 -> 170 ms); there the operand-scanning product keeps its N
+  // accumulators and only pins their order (msm_bls12_381.hip).
+#ifndef BZ_SW_ACCUMULATE_PINNED
+#define BZ_SW_ACCUMULATE_PINNED 1
+#endif
+  static constexpr bool accumulate_pinned = BZ_SW_ACCUMULATE_PINNED != 0 && G29::N <= 9;
   static constexpr bool has_batched_prepare = false;
   static constexpr bool has_wave_encode = false;
   static constexpr bool has_wave_add_multiple = false;
@@ -273,7 +282,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   BZ_HD static point dbl_n(const point& a, int k) { return G29::dbl_n(a, k); }
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     if (G29::is_identity_addend(q)) return;
-    acc = G29::add_mixed(acc, G29::unpack(q), negate);
+    acc = G29::template add_mixed<accumulate_pinned>(acc, G29::unpack(q), negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];

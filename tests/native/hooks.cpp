@@ -347,7 +347,10 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
 // limb-level contract is asserted while the tests run
 #define BZ_SW29_HOOKS(PFX, G)                                                                      \
   void bz_##PFX##_29_field_mul(u64* h, const u64* f, const u64* g) {                               \
-    G::F::to_mont64(h, G::F::mul(G::F::from_mont64(f), G::F::from_mont64(g)));                     \
+    const auto a = G::F::from_mont64(f), b = G::F::from_mont64(g);                                  \
+    const auto slow = G::F::mul(a, b), fast = G::F::mul_pinned(a, b);                              \
+    if (std::memcmp(&slow, &fast, sizeof(slow)) != 0) std::abort(); /* product scanning == */      \
+    G::F::to_mont64(h, slow);                                                                      \
   }                                                                                                \
   void bz_##PFX##_29_field_roundtrip(u64* h, const u64* f) {                                       \
     G::F::to_mont64(h, G::F::from_mont64(f));                                                      \
@@ -361,6 +364,8 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
     const auto fa = F::from_mont64(a), fb = F::from_mont64(b), fc = F::from_mont64(c),             \
                fd = F::from_mont64(d);                                                             \
     const auto lhs = F::mul2(F::add(fa, fa), fb, fc, F::add(F::add(fd, fd), fd));                  \
+    const auto scan = F::mul2_pinned(F::add(fa, fa), fb, fc, F::add(F::add(fd, fd), fd));          \
+    if (std::memcmp(&lhs, &scan, sizeof(lhs)) != 0) std::abort();                                  \
     F::to_mont64(h, lhs);                                                                          \
   }                                                                                                \
   void bz_##PFX##_29_add(u64* out, const u64* a, const u64* b) {                                   \
@@ -385,7 +390,10 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
     constexpr int W = G::N64;                                                                      \
     for (int i = 0; i < n; ++i) {                                                                  \
       G::affine q = G::affine_from_mont64(affine_xy + 2 * W * i, affine_xy + 2 * W * i + W, false); \
+      /* alternate between the two forms of the field products: both must give the same limbs */    \
+      const G::point fast = G::template add_mixed<true>(acc, q, negate[i] != 0);                   \
       acc = G::add_mixed(acc, q, negate[i] != 0);                                                  \
+      if (std::memcmp(&fast, &acc, sizeof(acc)) != 0) std::abort();                                \
     }                                                                                              \
     G::G64::point r = G::to_point64(acc);                                                          \
     std::memcpy(out, &r, sizeof(r));                                                               \
