@@ -61,7 +61,39 @@ def parse_args():
                     help="skip the reference-CPU leg (and with it the output verification)")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/4/5 legs")
     ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--dry-run-one-gpu", action="store_true",
+                    help="self-test of the N > 1 control flow on a one-GPU box: every rank uses "
+                         "cuda:0 and the collectives go through gloo on host copies (never a "
+                         "measurement)")
     return ap.parse_args()
+
+
+class Collectives:
+    """the three collectives of the bench: RCCL on device tensors, or (dry run) gloo on host copies"""
+
+    def __init__(self, dist, host):
+        self.dist = dist
+        self.host = host
+
+    def all_gather(self, dst, src):
+        if not self.host:
+            self.dist.all_gather_into_tensor(dst, src)
+            return
+        torch.cuda.synchronize()
+        parts = [torch.empty_like(src, device="cpu") for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(parts, src.cpu())
+        dst.copy_(torch.cat(parts, dim=0).to(dst.device))
+
+    def all_reduce(self, t, op):
+        if not self.host:
+            self.dist.all_reduce(t, op=op)
+            return
+        c = t.cpu()
+        self.dist.all_reduce(c, op=op)
+        t.copy_(c.to(t.device))
+
+    def barrier(self):
+        self.dist.barrier()
 
 
 def vp(t):
@@ -295,7 +327,7 @@ def run_configs(lib, oracle, args, dev, stream):
     return entries
 
 
-def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist):
+def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll):
     """N > 1: config 4's 256 columns sharded over the ranks (strong scaling), one all-gather of
     the 72-byte commitments"""
     cid, n, columns = 2, 1 << 20, 256
@@ -314,20 +346,20 @@ def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist):
 
     def step():
         lib.bzamd_msm_device(cid, vp(out), per, desc, vp(gens), stream)
-        dist.all_gather_into_tensor(gathered, out)
+        coll.all_gather(gathered, out)
 
     step()
     torch.cuda.synchronize()
-    dist.barrier()
+    coll.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.config_steps):
         step()
     torch.cuda.synchronize()
-    dist.barrier()
+    coll.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    coll.all_reduce(t, dist.ReduceOp.MAX)
     dt = float(t.item()) / args.config_steps
     # every rank checks its own shard inside the gathered result
     got = gathered.cpu().numpy()[begin:begin + per]
@@ -337,7 +369,7 @@ def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist):
         want = wl.expected_canonical(oracle, cid, base, wl.weighted_scalar_sum(sums, 0, 32))
         ok = ok and np.array_equal(got[c], want[:72])
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    coll.all_reduce(flag, dist.ReduceOp.MIN)
     assert int(flag.item()) == 1, "sharded config 4: a commitment differs from the reference"
     ops = world * per * n
     return {"config": f"4: bn254 G1, {world * per} columns x 2^20 rows sharded over {world} GPUs "
@@ -355,12 +387,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if args.dry_run_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    coll = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.dry_run_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        coll = Collectives(dist, args.dry_run_one_gpu)
     # one process per GPU: the library's own multi-device sharding stays off, this process drives
     # the device torch selected
     os.environ["BLITZAR_AMD_NUM_DEVICES"] = "1"
@@ -389,13 +428,13 @@ def main():
     def step():
         lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+            coll.all_gather(gathered, out)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        coll.barrier()
     torch.cuda.synchronize()
     clock = StageClock(lib, args.steps)
     t0 = time.perf_counter()
@@ -403,7 +442,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        coll.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     per_call, calls = clock.collect(args.steps)
@@ -430,7 +469,7 @@ def main():
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        coll.all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # every rank checks the commitment it timed against the reference CPU backend on the same
@@ -455,7 +494,7 @@ def main():
 
     sharded = None
     if world > 1 and oracle is not None and not args.no_configs and 256 % world == 0:
-        sharded = sharded_config4(lib, oracle, args, dev, stream, rank, world, dist)
+        sharded = sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -474,7 +513,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 limbs (9 x 29-bit GF(2^255-19), v_mad_u64_u32 products)",
             "data": "synthetic: std::mt19937{rank} bytes, uniform 252-bit scalars, generators "
-                    "compute_base_element(i) supplied by the caller on every call",
+                    "compute_base_element(i) supplied by the caller on every call"
+                    + (" [DRY RUN: all ranks on one GPU, gloo collectives -- not a measurement]"
+                       if args.dry_run_one_gpu else ""),
             "config": {"workload": name, "columns_per_gpu": 1, "rows": n,
                        "parallelism": f"columns x{world}"},
         }
@@ -530,7 +571,7 @@ def main():
 
     api.reset_for_testing()
     if world > 1:
-        dist.barrier()
+        coll.barrier()
         dist.destroy_process_group()
 
 
