@@ -268,6 +268,40 @@ def verify_inner_product(transcript, n, generators_offset, b_vector, product, a_
     return bool(rc), t
 
 
+class sumcheck_descriptor(ctypes.Structure):
+    _fields_ = [("mles", ctypes.c_void_p), ("product_table", ctypes.c_void_p),
+                ("product_terms", ctypes.c_void_p), ("n", ctypes.c_uint),
+                ("num_mles", ctypes.c_uint), ("num_products", ctypes.c_uint),
+                ("num_product_terms", ctypes.c_uint), ("round_degree", ctypes.c_uint)]
+
+
+SUMCHECK_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_uint)
+SUMCHECK_PRODUCT_STRIDE = {0: 36, 1: 40}  # std::pair<FIELD, unsigned> of the reference
+
+
+def prove_sumcheck(field_id, mles, product_table, product_terms, n, round_degree, callback):
+    """sxt_prove_sumcheck.  mles: uint8 [num_mles, n, 32]; product_table: raw bytes of
+    num_products x {32-byte multiplier; unsigned length}; callback(r_ptr, ctx, poly_ptr, length).
+    -> (polynomials [num_variables, round_degree + 1, 32], evaluation_point [num_variables, 32])"""
+    m = np.ascontiguousarray(mles, dtype=np.uint8)
+    table = np.ascontiguousarray(product_table, dtype=np.uint8)
+    terms = np.ascontiguousarray(product_terms, dtype=np.uint32)
+    num_variables = max((int(n) - 1).bit_length(), 1)
+    polys = np.zeros((num_variables, round_degree + 1, 32), dtype=np.uint8)
+    point = np.zeros((num_variables, 32), dtype=np.uint8)
+    d = sumcheck_descriptor(m.ctypes.data, table.ctypes.data, terms.ctypes.data, n, m.shape[0],
+                            table.size // SUMCHECK_PRODUCT_STRIDE[field_id], terms.size,
+                            round_degree)
+    cb = SUMCHECK_CALLBACK(callback)
+    fn = load().sxt_prove_sumcheck
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
+                   ctypes.POINTER(sumcheck_descriptor), SUMCHECK_CALLBACK, ctypes.c_void_p]
+    fn.restype = None
+    fn(_ptr(polys), _ptr(point), field_id, ctypes.byref(d), cb, None)
+    return polys, point
+
+
 class MultiexpHandle:
     """sxt_multiexp_handle wrapper (fixed generators)."""
 

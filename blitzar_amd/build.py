@@ -27,6 +27,7 @@ SOURCES = [
     "msm/context.hip",
     "generators/builtin.hip",
     "proof/inner_product.hip",
+    "proof/sumcheck.hip",
     "api/capi.hip",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + ROOT,

@@ -20,6 +20,7 @@
 #include "blitzar_amd/csrc/fixed/dump.h"
 #include "blitzar_amd/csrc/fixed/handle.h"
 #include "blitzar_amd/csrc/proof/inner_product.h"
+#include "blitzar_amd/csrc/proof/sumcheck.h"
 #include "blitzar_amd/csrc/proof/transcript.h"
 #include "include/blitzar_amd.h"
 
@@ -926,8 +927,7 @@ void bzamd_fixed_packed_multiexponentiation_device(void* res,
 }
 
 //--------------------------------------------------------------------------------------------------
-// inner-product argument (proof/inner_product.hip); the sumcheck prover stays a link-compatible
-// stub that aborts when called
+// inner-product argument (proof/inner_product.hip) and sumcheck prover (proof/sumcheck.hip)
 //--------------------------------------------------------------------------------------------------
 void sxt_curve25519_prove_inner_product(struct sxt_ristretto255_compressed* l_vector,
                                         struct sxt_ristretto255_compressed* r_vector,
@@ -982,10 +982,23 @@ int sxt_curve25519_verify_inner_product(struct sxt_transcript* transcript, uint6
              : 0;
 }
 
-void sxt_prove_sumcheck(void*, void*, unsigned, const struct sumcheck_descriptor*, void*, void*) {
-  std::fprintf(stderr,
-               "blitzar_amd: sxt_prove_sumcheck is outside the MSM path and not implemented\n");
-  std::abort();
+void sxt_prove_sumcheck(void* polynomials, void* evaluation_point, unsigned field_id,
+                        const struct sumcheck_descriptor* descriptor, void* transcript_callback,
+                        void* transcript_context) {
+  BZ_RELEASE_ASSERT(polynomials != nullptr && evaluation_point != nullptr && descriptor != nullptr &&
+                        transcript_callback != nullptr,
+                    "null argument to `sxt_prove_sumcheck`");
+  BZ_RELEASE_ASSERT(descriptor->mles != nullptr && descriptor->product_table != nullptr &&
+                        descriptor->product_terms != nullptr,
+                    "null table in the sumcheck descriptor");
+  api_state& st = state();
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const proof::sumcheck_inputs in{descriptor->mles,         descriptor->product_table,
+                                  descriptor->product_terms, descriptor->n,
+                                  descriptor->num_mles,      descriptor->num_products,
+                                  descriptor->num_product_terms, descriptor->round_degree};
+  proof::prove_sumcheck(st, polynomials, evaluation_point, field_id, in, transcript_callback,
+                        transcript_context);
 }
 
 //--------------------------------------------------------------------------------------------------

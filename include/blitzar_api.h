@@ -5,8 +5,8 @@
  * error behaviour are identical so that `blitzar-sys` (bindgen over the reference header,
  * rust/blitzar-sys/src/lib.rs:1-5) and C callers (example/cbindings1/main.cc) link against
  * `libblitzar_amd.so` unchanged.  Only the MSM / commitment path is implemented natively
- * (SURVEY.md section 8); the inner-product and sumcheck provers are exported for link
- * compatibility and abort when called.
+ *  together with its two consumers in the same header, the inner-product
+ * argument and the sumcheck prover.
  *
  * Error convention (reference: SXT_RELEASE_ASSERT -> std::abort, sxt/base/error/assert.h:51-58):
  * functions returning `void` abort the process on misuse; there is no errno and no exception
@@ -118,7 +118,10 @@ struct sxt_sequence_descriptor {
   int is_signed;
 };
 
-/* ref:147-181  (sumcheck; not on the MSM path) */
+/* ref:147-181  sumcheck polynomial  sum_p mult_p * prod_{j in terms_p} f_j(X_1 .. X_r):
+ * mles = n x num_mles FIELD elements, column-major; product_table = num_products entries
+ * {FIELD multiplier; unsigned product_length} (36 bytes for SXT_FIELD_SCALAR255, 40 for
+ * SXT_FIELD_GRUMPKIN: the reference's std::pair<FIELD, unsigned>); product_terms = MLE indices */
 struct sumcheck_descriptor {
   const void* mles;
   const void* product_table;
@@ -175,7 +178,10 @@ int sxt_ristretto255_get_generators(struct sxt_ristretto255* generators, uint64_
 /* ref:477  one_commit = g_0 + ... + g_{n-1} (identity for n = 0) */
 int sxt_curve25519_get_one_commit(struct sxt_ristretto255* one_commit, uint64_t n);
 
-/* ref:568, 606  link compatibility only: abort when called */
+/* ref:568, 606  inner-product argument over the built-in generators [generators_offset,
+ * generators_offset + np), np = 2^ceil(log2 n), Q = generator generators_offset + np.  l_vector /
+ * r_vector: ceil(log2 n) compressed points; the 203-byte transcript is updated in place.  Proof
+ * bytes and transcript state are identical to the reference's. */
 void sxt_curve25519_prove_inner_product(struct sxt_ristretto255_compressed* l_vector,
                                         struct sxt_ristretto255_compressed* r_vector,
                                         struct sxt_curve25519_scalar* ap_value,
@@ -225,7 +231,10 @@ void sxt_fixed_vlen_multiexponentiation(void* res, const struct sxt_multiexp_han
                                         const unsigned* output_lengths, unsigned num_outputs,
                                         const uint8_t* scalars);
 
-/* ref:766  link compatibility only: aborts when called */
+/* ref:766  polynomials: (round_degree + 1) x num_variables FIELD elements, column-major;
+ * evaluation_point: num_variables FIELD elements; transcript_callback:
+ *   void (FIELD* r, void* context, const FIELD* polynomial, unsigned polynomial_length)
+ * draws the round challenge.  round_degree <= 8 here (Limits). */
 void sxt_prove_sumcheck(void* polynomials, void* evaluation_point, unsigned field_id,
                         const struct sumcheck_descriptor* descriptor, void* transcript_callback,
                         void* transcript_context);

@@ -34,7 +34,7 @@ INC = re.compile(r'^\s*#\s*include\s+"(sxt/[^"]+)"', re.M)
 # compiled on the host; the drivers define what they need from them (ref_inner_product.cc)
 SKIP = {"sxt/scalar25/operation/inner_product.cc", "sxt/base/device/state.cc",
         "sxt/base/device/property.cc", "sxt/base/log/log_impl.cc", "sxt/base/log/setup.cc"}
-DRIVERS = ["ref_driver.cc", "ref_inner_product.cc"]
+DRIVERS = ["ref_driver.cc", "ref_inner_product.cc", "ref_sumcheck.cc"]
 
 
 def closure(root_file):

@@ -247,3 +247,33 @@ def s25_inner_product(a_vector, b_vector):
     out = np.zeros(32, dtype=np.uint8)
     lib().ref_s25_inner_product(_p(out), _p(a), _p(b), ctypes.c_uint64(min(a.shape[0], b.shape[0])))
     return out
+
+
+#--------------------------------------------------------------------------------------------------
+# sumcheck (oracle/ref/ref_sumcheck.cc: the reference's own prover with its cpu driver)
+#--------------------------------------------------------------------------------------------------
+SUMCHECK_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_uint)
+
+
+def sumcheck_product_stride(field_id):
+    return int(lib().ref_sumcheck_product_stride(ctypes.c_uint(field_id)))
+
+
+def prove_sumcheck(field_id, mles, product_table, product_terms, n, round_degree, callback):
+    """mles: uint8 [num_mles, n, 32] (column-major n x num_mles); product_table: raw bytes of
+    num_products x {element; unsigned}; callback(r_ptr, ctx, polynomial_ptr, length)."""
+    m = np.ascontiguousarray(mles, dtype=np.uint8)
+    num_mles = m.shape[0]
+    table = np.ascontiguousarray(product_table, dtype=np.uint8)
+    terms = np.ascontiguousarray(product_terms, dtype=np.uint32)
+    num_products = table.size // sumcheck_product_stride(field_id)
+    num_variables = max((int(n) - 1).bit_length(), 1)
+    polys = np.zeros((num_variables, round_degree + 1, 32), dtype=np.uint8)
+    point = np.zeros((num_variables, 32), dtype=np.uint8)
+    cb = SUMCHECK_CALLBACK(callback)
+    lib().ref_prove_sumcheck(_p(polys), _p(point), ctypes.c_uint(field_id), _p(m), _p(table),
+                             _p(terms), ctypes.c_uint(n), ctypes.c_uint(num_mles),
+                             ctypes.c_uint(num_products), ctypes.c_uint(terms.size),
+                             ctypes.c_uint(round_degree), cb, None)
+    return polys, point

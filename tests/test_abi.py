@@ -131,10 +131,10 @@ def test_environment_override_of_backend():
     assert r.returncode == 0 and r.stdout.strip() == "1", r.stderr
 
 
-def test_out_of_scope_provers_are_link_compatible_stubs():
-    r = _run_child("from blitzar_amd import api\nlib = api.load()\n"
+def test_sumcheck_rejects_null_arguments_loudly():
+    r = _run_child("from blitzar_amd import api\nlib = api.load()\napi.init(1, 0)\n"
                    "lib.sxt_prove_sumcheck(None, None, 0, None, None, None)\n")
-    assert r.returncode < 0 and "outside the MSM path" in r.stderr
+    assert r.returncode < 0 and "sxt_prove_sumcheck" in r.stderr
 
 
 def test_gpu_backend_without_gpu_fails_loudly():
