@@ -32,6 +32,13 @@ SOURCES = [
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + ROOT,
          "-Wno-unused-result"]
+# A/B variants (tools/prof/ab_env.sh): BZ_VARIANT=<tag> builds blitzar_amd/lib/variants/<tag>/ with
+# BZ_EXTRA_FLAGS (e.g. "-DBZ_F29_MAD_MODE=0") appended; the default library is untouched
+VARIANT = os.environ.get("BZ_VARIANT")
+if VARIANT:
+    OUT = os.path.join(OUT, "variants", VARIANT)
+    LIB = os.path.join(OUT, "libblitzar_amd.so")
+    FLAGS = FLAGS + os.environ.get("BZ_EXTRA_FLAGS", "").split()
 
 
 def _headers():

@@ -78,6 +78,15 @@ template <class P> struct mont29 {
     return h;
   }
 
+  // materialise the limbs here (device code; see f29::pin)
+  BZ_HD static void pin(fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a.v[i]));
+#else
+    (void)a;
+#endif
+  }
   BZ_HD static fe add(const fe& a, const fe& b) {
     fe h;
 #pragma unroll

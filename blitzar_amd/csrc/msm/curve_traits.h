@@ -44,7 +44,10 @@ struct ed25519_msm {
   // addend, prefetched next addend, product temporaries)
   // (measured on MI355X at config 2: 2 / 3 / 4 waves per SIMD -> 0.862 / 0.860 / 1.13 ms, the last
   // one spills: the kernel is issue-bound, not latency-bound)
-  static constexpr int accumulate_waves_per_simd = 3;
+#ifndef BZ_ACC_WAVES_ED
+#define BZ_ACC_WAVES_ED 3
+#endif
+  static constexpr int accumulate_waves_per_simd = BZ_ACC_WAVES_ED;
   static constexpr bool has_batched_prepare = false;
 
   BZ_HD static point identity() { return ed29::identity(); }
@@ -53,6 +56,20 @@ struct ed25519_msm {
   BZ_HD static point neg(const point& a) { return ed29::neg(a); }
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     acc = ed29::add_cached(acc, ed29::unpack(q), negate);
+  }
+  // k_accumulate's pipeline: the gathered row is unpacked at the top of the iteration (`stage`,
+  // pinned: the staging registers are free for the next gather), the addition consumes limbs
+  using operand = ed29_cached;
+  BZ_HD static operand stage(const addend& q) {
+    operand o = ed29::unpack(q);
+    f29::pin(o.YpX);
+    f29::pin(o.YmX);
+    f29::pin(o.Z);
+    f29::pin(o.T2d);
+    return o;
+  }
+  BZ_HD static void accumulate(point& acc, const operand& q, bool negate) {
+    acc = ed29::add_cached(acc, q, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     return ed29::pack(ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]));
@@ -170,6 +187,14 @@ struct ed25519_niels_msm : ed25519_msm {
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     acc = ed29::add_niels(acc, q, negate);
   }
+  using operand = ed29_niels; // stored as limbs: nothing to unpack
+  BZ_HD static operand stage(const addend& q) {
+    operand o = q;
+    f29::pin(o.YpX);
+    f29::pin(o.YmX);
+    f29::pin(o.T2d);
+    return o;
+  }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     return ed29::to_niels(ed29::from_ed(static_cast<const ed_point*>(api_generators)[i]));
   }
@@ -216,7 +241,10 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   using api_affine = sw_api_affine<N64>;
   static constexpr size_t api_generator_size = sizeof(api_affine);
   static constexpr size_t projective_size = sizeof(api_projective);
-  static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? 3 : 2;
+#ifndef BZ_ACC_WAVES_SW9
+#define BZ_ACC_WAVES_SW9 3
+#endif
+  static constexpr int accumulate_waves_per_simd = G29::N <= 9 ? BZ_ACC_WAVES_SW9 : 2;
   // k_accumulate's additions use the pinned product-scanning field products (field/mont29.h) on the
   // 9-limb curves: config 4 accumulate 348.3 -> 338.8 ms, config 5 138.1 -> 135.1 (A/B on one box,
   // profiles/round2_ab_pinned_products.log).  With 14 limbs the quotient digits and the single
@@ -283,6 +311,21 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     if (G29::is_identity_addend(q)) return;
     acc = G29::template add_mixed<accumulate_pinned>(acc, G29::unpack(q), negate);
+  }
+  // k_accumulate's pipeline (see ed25519_msm::stage)
+  struct operand {
+    typename G29::affine a;
+    bool skip; // the identity's all-zero row
+  };
+  BZ_HD static operand stage(const addend& q) {
+    operand o{G29::unpack(q), G29::is_identity_addend(q)};
+    F29::pin(o.a.x);
+    F29::pin(o.a.y);
+    return o;
+  }
+  BZ_HD static void accumulate(point& acc, const operand& q, bool negate) {
+    if (q.skip) return;
+    acc = G29::template add_mixed<accumulate_pinned>(acc, q.a, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];

@@ -923,6 +923,9 @@ template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 d
   return r;
 }
 
+#ifndef BZ_ACC_PIPELINE
+#define BZ_ACC_PIPELINE 2
+#endif
 template <class C>
 __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_simd)
     k_accumulate(typename C::point* __restrict__ bucket_sums, typename C::point* __restrict__ heads,
@@ -945,6 +948,49 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   const u32* idx = sorted + task.entry_base;
   typename C::point* sums = bucket_sums + task.bucket_base;
   typename C::point acc = C::identity();
+#if BZ_ACC_PIPELINE == 2
+  // Software pipeline, one entry ahead, with no register copies: at the top of an iteration the
+  // staged row (the packed words the previous iteration's gather delivered) is turned into the
+  // operand the addition consumes -- pinned there, so the staging registers are dead before the
+  // next gather is issued into them -- and that gather then has the whole addition (~1500 VALU
+  // instructions) to land.  (The first version carried the packed row through the addition and
+  // copied next -> current at the loop end: 33 v_mov_b64 + ~100 v_mov_b32 per iteration.)
+  //
+  // Bucket boundaries: with 64 lanes and ~1 boundary per 32 entries, SOME lane of the wavefront
+  // flushes in ~87 % of the iterations, so the whole wavefront walks the flush block almost every
+  // time.  It is therefore one store sequence to a selected destination (the bucket's sum if the
+  // bucket started in this segment, else this segment's head partial), and the end of the next
+  // bucket is fetched an iteration ahead instead of being waited for inside the block (fetched by
+  // every iteration, outside the divergent block: issued inside it, hipcc waits for it on the spot
+  // to merge it into the lanes that did not flush).
+  const u32 last_bucket = task.num_buckets - 1;
+  u32 next_end = ends[b < last_bucket ? b + 1 : last_bucket];
+  typename C::point* flush_to = owned ? sums + b : heads + task.segment_base + seg;
+  u32 e_cur = idx[lo];
+  u32 e_next = lo + 1 < hi ? idx[lo + 1] : 0;
+  typename C::addend staged = addends[e_cur & 0x7fffffffu];
+  for (u32 i = lo; i < hi; ++i) {
+    if (i == b_end) {
+      *flush_to = acc;
+      ++b;
+      b_end = next_end;
+      while (b_end == i) { // empty buckets
+        ++b;
+        b_end = ends[b];
+      }
+      flush_to = sums + b;
+      owned = true;
+      acc = C::identity();
+    }
+    next_end = ends[b < last_bucket ? b + 1 : last_bucket];
+    const typename C::operand q = C::stage(staged);
+    const bool negate = (e_cur >> 31) != 0;
+    e_cur = e_next;
+    if (i + 1 < hi) staged = addends[e_cur & 0x7fffffffu];
+    if (i + 2 < hi) e_next = idx[i + 2];
+    C::accumulate(acc, q, negate);
+  }
+#else
   // software pipeline, one entry ahead: the gather of the next addend (two dependent loads:
   // index, then 144..192 bytes from a random row of the generator table) is in flight while the
   // current addition (~1500 VALU instructions) executes, so a wave hides its own memory latency
@@ -973,6 +1019,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
     if (i + 2 < hi) e_after = idx[i + 2];
     C::accumulate(acc, q, (e >> 31) != 0);
   }
+#endif
   // runs of `whole` lanes (necessarily of one bucket) -> one head per run and wavefront
   const unsigned long long whole_mask = __ballot(whole);
   const u32 lane = threadIdx.x & 63;
@@ -985,11 +1032,15 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
     }
     if (whole && lane != 0 && ((whole_mask >> (lane - 1)) & 1) != 0) write_head = false;
   }
+#if BZ_ACC_PIPELINE == 2
+  if (owned || write_head) *flush_to = acc;
+#else
   if (owned) {
     sums[b] = acc;
   } else if (write_head) {
     heads[task.segment_base + seg] = acc;
   }
+#endif
 }
 
 // complete sum of bucket b of a task: the owner's partial plus the heads of the following
