@@ -92,6 +92,8 @@ def load():
     lib.bzamd_reset_for_testing.restype = None
     lib.bzamd_set_tuning.argtypes = [u32, u64, u64]
     lib.bzamd_set_tuning.restype = None
+    lib.bzamd_set_segments.argtypes = [u32, u32]
+    lib.bzamd_set_segments.restype = None
     lib.bzamd_stage_timing_begin.argtypes = [u64]
     lib.bzamd_stage_timing_begin.restype = None
     lib.bzamd_stage_timing_collect.argtypes = [ctypes.POINTER(ctypes.c_double)]

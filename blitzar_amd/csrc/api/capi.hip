@@ -1052,6 +1052,14 @@ void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
                          max_workspace_bytes);
 }
 
+void bzamd_set_segments(uint32_t log2_entries_per_accumulate_lane,
+                        uint32_t log2_buckets_per_reduce_lane) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "tuning applies to the GPU backend");
+  msm_context_set_segments(st.context_for_current_device(), log2_entries_per_accumulate_lane,
+                           log2_buckets_per_reduce_lane);
+}
+
 void bzamd_reset_for_testing(void) {
   if (g_state == nullptr) return;
   delete g_state;

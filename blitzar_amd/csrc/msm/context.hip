@@ -34,6 +34,19 @@ msm_context* msm_context_new() {
   if (const char* v = std::getenv("BLITZAR_AMD_MAX_WINDOW_BITS")) {
     msm_context_set_tuning(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)), 0, 0);
   }
+  if (const char* v = std::getenv("BLITZAR_AMD_BUCKET_COST")) {
+    const double cost = std::strtod(v, nullptr);
+    BZ_RELEASE_ASSERT(cost > 0 && cost < 1e6, "BLITZAR_AMD_BUCKET_COST must be positive");
+    ctx->tuning.throughput_bucket_cost = cost;
+  }
+  if (const char* v = std::getenv("BLITZAR_AMD_REDUCE_SEGMENT_LOG2")) {
+    msm_context_set_segments(ctx, ctx->tuning.force_segment_log2,
+                             static_cast<u32>(std::strtoul(v, nullptr, 10)));
+  }
+  if (const char* v = std::getenv("BLITZAR_AMD_SEGMENT_LOG2")) {
+    msm_context_set_segments(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)),
+                             ctx->tuning.force_reduce_segment_log2);
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_FORCE_WINDOW_TABLES")) {
     ctx->tuning.force_window_tables = v[0] != '0';
   }
@@ -52,6 +65,16 @@ void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_ta
     ctx->tuning.max_tasks_per_batch = max_tasks_per_batch;
   }
   if (max_workspace_bytes != 0) ctx->tuning.max_workspace_bytes = max_workspace_bytes;
+}
+void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_lane,
+                              u32 log2_buckets_per_reduce_lane) {
+  BZ_RELEASE_ASSERT(log2_entries_per_accumulate_lane == 0 ||
+                        (log2_entries_per_accumulate_lane >= 3 && log2_entries_per_accumulate_lane <= 10),
+                    "entries per accumulate lane: 2^3 .. 2^10 (0 = automatic)");
+  BZ_RELEASE_ASSERT(log2_buckets_per_reduce_lane <= 8,
+                    "buckets per reduce lane: 2^1 .. 2^8 (0 = automatic)");
+  ctx->tuning.force_segment_log2 = log2_entries_per_accumulate_lane;
+  ctx->tuning.force_reduce_segment_log2 = log2_buckets_per_reduce_lane;
 }
 void msm_context_timing_begin(msm_context* ctx, size_t max_calls) {
   std::lock_guard<std::mutex> lock(ctx->mu);

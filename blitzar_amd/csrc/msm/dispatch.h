@@ -84,6 +84,10 @@ void msm_context_free(msm_context* ctx);
 // per batch of columns
 void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
                             size_t max_workspace_bytes);
+// sorted entries per k_accumulate lane = 2^a (3..10), buckets per k_reduce lane = 2^r (1..8);
+// 0 = chosen per launch from its entry / bucket counts (plan.h)
+void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_lane,
+                              u32 log2_buckets_per_reduce_lane);
 // per-stage HIP-event timing of the next `max_calls` MSM calls on this context
 void msm_context_timing_begin(msm_context* ctx, size_t max_calls);
 // accumulated ms per stage {prepare, recode, sort, accumulate, reduce, combine}; returns #calls

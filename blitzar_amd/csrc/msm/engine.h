@@ -168,7 +168,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
 }
 
 static inline u32 partial_stride_of(const msm_plan& plan) {
-  return plan.max_task_buckets == 0 ? 1 : ceil_div_u32(plan.max_task_buckets, kReduceBlockBuckets);
+  return plan.max_task_buckets == 0 ? 1 : ceil_div_u32(plan.max_task_buckets, plan.reduce_block_buckets());
 }
 
 template <class C>
@@ -317,7 +317,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
                        static_cast<const point*>(nullptr), 1u, b.cols,
                        static_cast<const task_desc*>(nullptr), static_cast<const u32*>(nullptr), 0u,
-                       0u, 1, 1);
+                       0u, 1, 1, plan.reduce_segment_log2);
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipGetLastError());
     return;
@@ -356,7 +356,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.horner_state = ctx.arena.take<point>(num_cols);
   const size_t part_lds = sizeof(u32) * plan.max_task_groups;
   const u32 seg_blocks =
-      ceil_div_u32(plan.max_task_rows, static_cast<u64>(kSegmentEntries) * kAccumulateThreads);
+      ceil_div_u32(plan.max_task_rows, static_cast<u64>(kAccumulateThreads) << plan.segment_log2);
 
   // One stream, stages in order.  (Running the sort of window group k+1 and the reduce / Horner of
   // group k-1 on side streams under the accumulation of group k was measured on MI355X and is
@@ -420,13 +420,14 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   ctx.timer.timed(timing, 4, stream, [&] {
     hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
                        stream, b.partials, b.partial_stride, b.bucket_sums, b.heads, b.bucket_end,
-                       b.tasks);
+                       b.tasks, plan.reduce_segment_log2);
   });
   // whole columns in one launch: the range covers every window, first and last
   ctx.timer.timed(timing, 5, stream, [&] {
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
-                       b.partial_stride, b.cols, b.tasks, b.bucket_end, 0u, 0xffffffffu, 1, 1);
+                       b.partial_stride, b.cols, b.tasks, b.bucket_end, 0u, 0xffffffffu, 1, 1,
+                       plan.reduce_segment_log2);
   });
   if (timing) ctx.timer.calls += 1;
   g_kernel_launches += 10;

@@ -650,6 +650,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
   lds_barrier();
   u32* out = sorted + task.entry_base + begin;
   u32* seg = segment_bucket + task.segment_base;
+  const u32 seg_log2 = task.segment_log2, seg_mask = (1u << seg_log2) - 1;
   u32 pos[kLocalSortPerThread];
   if (staged) {
 #pragma unroll
@@ -663,8 +664,8 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
       if (tid + k * kGroupSortThreads < total) {
         staging[pos[k]] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
-        if ((begin + pos[k]) % kSegmentEntries == 0) {
-          seg[(begin + pos[k]) / kSegmentEntries] = (g << s) + ((mine[k] >> shift) & in_group);
+        if (((begin + pos[k]) & seg_mask) == 0) {
+          seg[(begin + pos[k]) >> seg_log2] = (g << s) + ((mine[k] >> shift) & in_group);
         }
       }
     }
@@ -688,8 +689,8 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       for (u32 k = 0; k < kLocalSortPerThread; ++k) {
         if (base + tid + k * kGroupSortThreads < total) {
           out[pos[k]] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
-          if ((begin + pos[k]) % kSegmentEntries == 0) {
-            seg[(begin + pos[k]) / kSegmentEntries] = (g << s) + ((mine[k] >> shift) & in_group);
+          if (((begin + pos[k]) & seg_mask) == 0) {
+            seg[(begin + pos[k]) >> seg_log2] = (g << s) + ((mine[k] >> shift) & in_group);
           }
         }
       }
@@ -885,12 +886,13 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       lds_barrier();
       u32* out = sorted + task.entry_base + group_begin;
       u32* seg = segment_bucket + task.segment_base;
+      const u32 seg_log2 = task.segment_log2, seg_mask = (1u << seg_log2) - 1;
       for (u32 i = tid; i < total; i += kGroupSortThreads) {
         const u32 b = staged_bucket[i];
         const u32 at = run_base[b] + (i - local_start[b]); // group-relative position
         out[at] = staging[i];
-        if ((group_begin + at) % kSegmentEntries == 0) {
-          seg[(group_begin + at) / kSegmentEntries] = (g << s) + b;
+        if (((group_begin + at) & seg_mask) == 0) {
+          seg[(group_begin + at) >> seg_log2] = (g << s) + b;
         }
       }
       lds_barrier(); // the LDS arrays are reused by the next chunk
@@ -936,15 +938,16 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   const u32* ends = bucket_end + task.bucket_base;
   const u32 total = ends[task.num_buckets - 1];
   const u32 seg = blockIdx.x * kAccumulateThreads + threadIdx.x;
-  const u32 lo = seg * kSegmentEntries;
+  const u32 seg_entries = 1u << task.segment_log2; // 32, or more for throughput-bound launches
+  const u32 lo = seg << task.segment_log2;
   if (lo >= total) return;
-  const u32 hi = lo + kSegmentEntries < total ? lo + kSegmentEntries : total;
+  const u32 hi = lo + seg_entries < total ? lo + seg_entries : total;
   u32 b = segment_bucket[task.segment_base + seg];
   u32 b_end = ends[b];
   const u32 b_start = b == 0 ? 0 : ends[b - 1];
   bool owned = b_start == lo;
   // the whole segment lies inside a bucket that started in an earlier segment
-  const bool whole = !owned && b_end >= lo + kSegmentEntries;
+  const bool whole = !owned && b_end >= lo + seg_entries;
   const u32* idx = sorted + task.entry_base;
   typename C::point* sums = bucket_sums + task.bucket_base;
   typename C::point acc = C::identity();
@@ -1049,10 +1052,10 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
 template <class C>
 __device__ __forceinline__ typename C::point
 load_bucket(const typename C::point* __restrict__ sums, const typename C::point* __restrict__ heads,
-            u32 begin, u32 end, u32 b) {
+            u32 begin, u32 end, u32 b, u32 seg_log2) {
   typename C::point v = sums[b];
-  const u32 first = begin / kSegmentEntries, last = (end - 1) / kSegmentEntries;
-  const u32 after_whole = end / kSegmentEntries; // first segment not entirely below `end`
+  const u32 first = begin >> seg_log2, last = (end - 1) >> seg_log2;
+  const u32 after_whole = end >> seg_log2; // first segment not entirely below `end`
   u32 s = first + 1;
   while (s <= last) {
     v = C::add(v, heads[s]);
@@ -1075,9 +1078,9 @@ struct bucket_heads {
     return j == 0 ? s0 : (j <= middle ? (k_lo + j - 1) * 64 : tail_index);
   }
 };
-__device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end) {
-  const u32 first = begin / kSegmentEntries, last = (end - 1) / kSegmentEntries;
-  const u32 after_whole = end / kSegmentEntries;
+__device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end, u32 seg_log2) {
+  const u32 first = begin >> seg_log2, last = (end - 1) >> seg_log2;
+  const u32 after_whole = end >> seg_log2;
   bucket_heads h;
   h.s0 = first + 1;
   h.k_lo = h.s0 / 64 + 1;
@@ -1093,7 +1096,8 @@ __device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end) {
 // k_reduce
 //--------------------------------------------------------------------------------------------------
 // partial[task][block] = sum over the block's buckets of (b + 1) * bucket[b]; a block covers
-// 2048 consecutive buckets, lane t the kReduceSegment = 8 buckets from block_first + 8 t on.
+// 256 * 2^lane_log2 consecutive buckets, lane t the 2^lane_log2 buckets from block_first + t 2^lane_log2
+// on (8 per lane for a latency-bound launch, up to 64 for a throughput-bound one: plan.h).
 // Running sums over the lane's buckets give s_t = sum B_j and r_t = sum (j + 1) B_j.  The kernel
 // is bound by its total number of point additions (one wavefront per SIMD already keeps the
 // 64-bit multiplier busy), so what matters is how the weights of the lanes are applied:
@@ -1109,12 +1113,14 @@ __global__ void __launch_bounds__(kReduceThreads)
     k_reduce(typename C::point* __restrict__ partials, u32 partial_stride,
              const typename C::point* __restrict__ bucket_sums,
              const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
-             const task_desc* __restrict__ tasks) {
+             const task_desc* __restrict__ tasks, u32 lane_log2) {
   using point = typename C::point;
   __shared__ point tree[kReduceThreads];
   const task_desc task = tasks[blockIdx.y];
   const u32 nb = task.num_buckets;
-  const u32 block_first = blockIdx.x * kReduceBlockBuckets;
+  const u32 seg_log2 = task.segment_log2; // k_accumulate's segments: where the head partials are
+  const u32 lane_buckets = 1u << lane_log2;
+  const u32 block_first = blockIdx.x * (kReduceThreads << lane_log2);
   if (block_first >= nb) return;
   const u32 tid = threadIdx.x;
   const u32* ends = bucket_end + task.bucket_base;
@@ -1124,7 +1130,7 @@ __global__ void __launch_bounds__(kReduceThreads)
     if (tid == 0) *dst = C::identity();
     return;
   }
-  const u32 seg_first = block_first + tid * kReduceSegment;
+  const u32 seg_first = block_first + tid * lane_buckets;
   const point* bs = bucket_sums + task.bucket_base;
   const point* hd = heads + task.segment_base;
   // Heavy buckets first.  A bucket that holds a large share of a skewed column (constants,
@@ -1138,11 +1144,11 @@ __global__ void __launch_bounds__(kReduceThreads)
   if (tid == 0) heavy_count = 0;
   __syncthreads();
   if (seg_first < nb) {
-    const u32 seg_last = seg_first + kReduceSegment < nb ? seg_first + kReduceSegment : nb;
+    const u32 seg_last = seg_first + lane_buckets < nb ? seg_first + lane_buckets : nb;
     u32 begin = seg_first == 0 ? 0 : ends[seg_first - 1];
     for (u32 b = seg_first; b < seg_last; ++b) {
       const u32 end = ends[b];
-      if (end != begin && heads_of(begin, end).count > kReduceHeavyHeads) {
+      if (end != begin && heads_of(begin, end, seg_log2).count > kReduceHeavyHeads) {
         const u32 slot = atomicAdd(&heavy_count, 1u);
         if (slot < kReduceMaxHeavy) heavy_bucket[slot] = b;
       }
@@ -1153,7 +1159,7 @@ __global__ void __launch_bounds__(kReduceThreads)
   const u32 num_heavy = heavy_count < kReduceMaxHeavy ? heavy_count : kReduceMaxHeavy;
   for (u32 h = 0; h < num_heavy; ++h) {
     const u32 b = heavy_bucket[h];
-    const bucket_heads list = heads_of(b == 0 ? 0 : ends[b - 1], ends[b]);
+    const bucket_heads list = heads_of(b == 0 ? 0 : ends[b - 1], ends[b], seg_log2);
     point part = C::identity();
     bool any = false;
     for (u32 j = tid; j < list.count; j += kReduceThreads) {
@@ -1173,7 +1179,7 @@ __global__ void __launch_bounds__(kReduceThreads)
   point r = C::identity();
   bool populated = false;
   if (seg_first < nb) {
-    const u32 seg_last = seg_first + kReduceSegment < nb ? seg_first + kReduceSegment : nb;
+    const u32 seg_last = seg_first + lane_buckets < nb ? seg_first + lane_buckets : nb;
     const u32 lo = seg_first == 0 ? 0 : ends[seg_first - 1];
     const u32 hi = ends[seg_last - 1];
     if (hi != lo) {
@@ -1183,11 +1189,11 @@ __global__ void __launch_bounds__(kReduceThreads)
         const u32 begin = b == 0 ? 0 : ends[b - 1];
         if (begin != end) {
           u32 folded = kReduceMaxHeavy;
-          if (num_heavy != 0 && heads_of(begin, end).count > kReduceHeavyHeads) {
+          if (num_heavy != 0 && heads_of(begin, end, seg_log2).count > kReduceHeavyHeads) {
             for (u32 h = 0; h < num_heavy; ++h) folded = heavy_bucket[h] == b ? h : folded;
           }
           s = C::add(s, folded < kReduceMaxHeavy ? heavy_sum[folded]
-                                                 : load_bucket<C>(bs, hd, begin, end, b));
+                                                 : load_bucket<C>(bs, hd, begin, end, b, seg_log2));
         }
         r = C::add(r, s);
         end = begin;
@@ -1203,8 +1209,8 @@ __global__ void __launch_bounds__(kReduceThreads)
       if (tid + d < kReduceThreads) x = C::add(x, tree[tid + d]);
       __syncthreads();
     }
-    // v_t = r_t + kReduceSegment * suffix_t (t >= 1), folded by the tree
-    if (tid != 0) r = C::add(r, C::dbl_n(x, static_cast<int>(kReduceSegmentLog2)));
+    // v_t = r_t + 2^lane_log2 * suffix_t (t >= 1), folded by the tree
+    if (tid != 0) r = C::add(r, C::dbl_n(x, static_cast<int>(lane_log2)));
     tree[tid] = r;
     __syncthreads();
     for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
@@ -1264,7 +1270,7 @@ __global__ void __launch_bounds__(kCombineThreads)
              typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
              u32 partial_stride, const column_desc* __restrict__ columns,
              const task_desc* __restrict__ tasks, const u32* __restrict__ bucket_end, u32 w_lo_arg,
-             u32 w_hi_arg, int first, int last) {
+             u32 w_hi_arg, int first, int last, u32 reduce_seg_log2) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
   const column_desc col = columns[blockIdx.x];
@@ -1303,7 +1309,8 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 w = tid / team;
   const u32 lane = tid % team;
   const u32 nb = 1u << (col.window_bits - 1);
-  const u32 blocks = (nb + kReduceBlockBuckets - 1) / kReduceBlockBuckets;
+  const u32 reduce_block = kReduceThreads << reduce_seg_log2; // buckets per k_reduce block
+  const u32 blocks = (nb + reduce_block - 1) / reduce_block;
   point sum = C::identity();
   if (w < W && lane < blocks) {
     const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;

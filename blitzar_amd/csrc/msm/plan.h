@@ -25,7 +25,19 @@
 
 namespace bz {
 
-constexpr u32 kSegmentEntries = 32;       // sorted entries per accumulation lane
+// sorted entries per accumulation lane = 2^s (msm_plan::segment_log2): every segment that begins
+// inside a bucket leaves a head partial for k_reduce to add (one projective addition per segment),
+// so a launch with entries to spare (hundreds of columns) takes longer segments; a single column
+// keeps 32 so that its lanes fill the machine
+constexpr u32 kSegmentLog2 = 5;
+constexpr u32 kSegmentLog2Max = 7;
+constexpr u64 kSegmentFillLanes = u64{1} << 22; // lanes k_accumulate should still have (~20 rounds)
+constexpr u32 kSegmentEntries = 1u << kSegmentLog2;
+inline u32 choose_segment_log2(u64 total_entries) {
+  u32 s = kSegmentLog2;
+  while (s < kSegmentLog2Max && (total_entries >> (s + 1)) >= kSegmentFillLanes) ++s;
+  return s;
+}
 constexpr u32 kStagedSliceRows = 1u << 14; // rows per partition workgroup: staged in LDS / direct
 constexpr u32 kDirectSliceRows = 1u << 16;
 constexpr u32 kMaxStagedGroups = 1024;     // the staged partition keeps 3 counters per group in LDS
@@ -42,9 +54,27 @@ constexpr u32 kReduceThreads = BZ_REDUCE_THREADS;
 #ifndef BZ_REDUCE_SEGMENT_LOG2
 #define BZ_REDUCE_SEGMENT_LOG2 3
 #endif
-constexpr u32 kReduceSegmentLog2 = BZ_REDUCE_SEGMENT_LOG2; // buckets per k_reduce lane = 2^this
-constexpr u32 kReduceSegment = 1u << kReduceSegmentLog2;
-constexpr u32 kReduceBlockBuckets = kReduceThreads * kReduceSegment;
+// buckets per k_reduce lane = 2^s, chosen per launch (msm_plan::reduce_segment_log2): a lane pays
+// 2 additions per bucket plus ~30 per lane (its weight and the tree), so few buckets per lane keep
+// the dependent chain of a latency-bound launch short (one column: s = 3), many buckets per lane
+// keep the total work of a throughput-bound launch small (hundreds of columns: s = 6)
+constexpr u32 kReduceSegmentLog2 = BZ_REDUCE_SEGMENT_LOG2;
+#ifndef BZ_REDUCE_SEGMENT_LOG2_MAX
+#define BZ_REDUCE_SEGMENT_LOG2_MAX 6
+#endif
+constexpr u32 kReduceSegmentLog2Max = BZ_REDUCE_SEGMENT_LOG2_MAX;
+// lanes that fill the machine twice over (1024 SIMDs x 64 lanes x 2 waves)
+constexpr u64 kReduceFillLanes = 131072;
+inline u32 choose_reduce_segment_log2(u64 total_buckets, u32 max_task_buckets) {
+  u32 s = kReduceSegmentLog2;
+  // ... as long as the largest task still fills a block's 256 lanes (idle waves of a block hold
+  // registers the other blocks of the CU could use)
+  while (s < kReduceSegmentLog2Max && (total_buckets >> (s + 1)) >= kReduceFillLanes &&
+         (static_cast<u64>(kReduceThreads) << (s + 1)) <= max_task_buckets) {
+    ++s;
+  }
+  return s;
+}
 
 // device-visible task descriptor
 struct task_desc {
@@ -56,7 +86,7 @@ struct task_desc {
   u32 slice_rows;   // rows per partition workgroup (power of two, multiple of 8)
   u32 group_bits;   // s: a group is 2^s consecutive buckets
   u32 num_groups;   // num_buckets >> s
-  u32 pad;
+  u32 segment_log2; // sorted entries per k_accumulate lane = 2^this (one value per launch)
   u64 bucket_base;  // first bucket of this task in the flat bucket arrays
   u64 entry_base;   // first entry of this task in the flat digit / record / sorted-index arrays
   u64 group_base;   // first entry of this task's group tables (num_groups + 1 entries)
@@ -107,8 +137,14 @@ struct msm_plan {
   u32 max_task_groups = 0;
   u32 max_slice_rows = 0;
   u32 max_windows = 0;
+  u32 segment_log2 = kSegmentLog2;               // sorted entries per k_accumulate lane
+  u32 reduce_segment_log2 = kReduceSegmentLog2; // buckets per k_reduce lane (a block: 256 lanes)
+  u32 reduce_block_buckets() const { return kReduceThreads << reduce_segment_log2; }
 };
 
+#ifndef BZ_THROUGHPUT_BUCKET_COST
+#define BZ_THROUGHPUT_BUCKET_COST 3.5
+#endif
 struct msm_tuning {
   u32 max_window_bits = 16; // digits are stored as int16
   // batching of many-column jobs: tasks per launch (grid.y) and device workspace per batch
@@ -118,7 +154,9 @@ struct msm_tuning {
   u32 partition_group_entries = kGroupTargetEntries;
   // window-width cost model: from this many columns on, buckets cost `throughput_bucket_cost`
   size_t throughput_columns = 4;
-  double throughput_bucket_cost = 12.0;
+  double throughput_bucket_cost = BZ_THROUGHPUT_BUCKET_COST;
+  u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
+  u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
   // window tables: gathers from a table beyond the 256 MiB Infinity Cache cost this much more per
   // addition (measured on MI355X: 51 against 43 ps with a 2 GiB curve25519 table); a table that
   // fits costs `table_penalty_cached`.  `force_window_tables` (tests) merges whenever possible.
@@ -132,9 +170,12 @@ inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b)
 //   W * (n + bucket_cost * 2^(c-1)),  W = ceil((B + 1) / c)
 // where bucket_cost is the price of reducing one bucket in units of one bucket addition.  A
 // single column is latency-bound in k_reduce (few waves, the dependent chain is what matters): its
-// buckets are nearly free (2.5).  Many columns fill the machine with reduce work (measured on
-// MI355X, bn254, 32 x 2^20: 2.5 ns per bucket against 0.16 ns per addition), so buckets are priced
-// at their throughput cost and narrower windows win.
+// buckets are nearly free (2.5).  Many columns fill the machine with reduce work, so buckets are
+// priced at their throughput cost: with 64 buckets per reduce lane (choose_reduce_segment_log2)
+// that is two projective additions per bucket plus its share of the lane's ~30, measured on
+// MI355X (bn254, 256 x 2^20, c = 15 against 16: 16.5 ms for 71 M more buckets = 0.23 ns per bucket
+// against 0.07 ns per accumulated entry) as 3.5.  (Round 1, with 8 buckets per lane whatever the
+// launch: 15 additions per bucket, which had pushed such jobs to c = 13-14.)
 inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune, double bucket_cost = 2.5) {
   u32 best_c = 1;
   double best_cost = 1e300;
@@ -227,6 +268,31 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
   size_t nonempty = 0;
   for (const auto& c : cols) nonempty += c.n != 0 ? 1 : 0;
   const double bucket_cost = nonempty >= tune.throughput_columns ? tune.throughput_bucket_cost : 2.5;
+  // window width, window count and (virtual) rows per task of a column
+  struct column_shape {
+    bool merged;
+    u32 c, w;
+    u64 task_rows;
+  };
+  auto shape_of = [&](const host_column& hc) {
+    column_shape sh{};
+    sh.merged = use_window_table(hc, tables, tune, bucket_cost);
+    sh.c = sh.merged ? tables->bits : choose_window_bits(hc.n, hc.bit_width, tune, bucket_cost);
+    sh.w = ceil_div_u32(hc.bit_width + 1, sh.c);
+    // rows of a task: the column's, or every (window, row) pair up to the last window's rows
+    sh.task_rows = sh.merged ? static_cast<u64>(sh.w - 1) * tables->stride + hc.n : hc.n;
+    return sh;
+  };
+  // entries per accumulation lane: one value for the launch, from its total number of entries
+  u64 launch_entries = 0;
+  for (const auto& hc : cols) {
+    if (hc.n == 0) continue;
+    const column_shape sh = shape_of(hc);
+    launch_entries += sh.task_rows * (sh.merged ? 1 : sh.w);
+  }
+  plan.segment_log2 = tune.force_segment_log2 != 0 ? tune.force_segment_log2
+                                                   : choose_segment_log2(launch_entries);
+  const u64 seg_entries = u64{1} << plan.segment_log2;
   for (size_t ci = 0; ci < cols.size(); ++ci) {
     const host_column& hc = cols[ci];
     column_desc cd{};
@@ -243,13 +309,11 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       plan.columns.push_back(cd);
       continue;
     }
-    const u32 bits = hc.bit_width;
-    const bool merged = use_window_table(hc, tables, tune, bucket_cost);
-    const u32 c = merged ? tables->bits : choose_window_bits(hc.n, bits, tune, bucket_cost);
-    const u32 w = ceil_div_u32(bits + 1, c);
+    const column_shape sh = shape_of(hc);
+    const bool merged = sh.merged;
+    const u32 c = sh.c, w = sh.w;
     const u32 buckets = 1u << (c - 1);
-    // rows of a task: the column's, or every (window, row) pair up to the last window's rows
-    const u64 task_rows = merged ? static_cast<u64>(w - 1) * tables->stride + hc.n : hc.n;
+    const u64 task_rows = sh.task_rows;
     const partition_geometry geo =
         choose_partition(task_rows, c, tune.partition_group_entries);
     const u32 slices = geo.num_slices;
@@ -266,6 +330,7 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       t.num_slices = slices;
       t.slice_rows = geo.slice_rows;
       t.group_bits = geo.group_bits;
+      t.segment_log2 = plan.segment_log2;
       t.num_groups = geo.num_groups;
       t.bucket_base = plan.total_buckets;
       t.entry_base = plan.total_entries;
@@ -275,7 +340,7 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
       // keep every task's entry range 16-byte aligned for both the i16 and the u32 views
       plan.total_entries += (task_rows + 7) & ~7ull;
       plan.total_groups += geo.num_groups + 1;
-      plan.total_segments += (task_rows + kSegmentEntries - 1) / kSegmentEntries;
+      plan.total_segments += (task_rows + seg_entries - 1) / seg_entries;
       plan.tasks.push_back(t);
     }
     if (task_rows > plan.max_task_rows) plan.max_task_rows = task_rows;
@@ -289,6 +354,9 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     if (hc.n > plan.max_rows) plan.max_rows = hc.n;
     plan.columns.push_back(cd);
   }
+  plan.reduce_segment_log2 = tune.force_reduce_segment_log2 != 0
+                                 ? tune.force_reduce_segment_log2
+                                 : choose_reduce_segment_log2(plan.total_buckets, plan.max_task_buckets);
   return plan;
 }
 

@@ -60,6 +60,13 @@ void bzamd_reset_for_testing(void);
  * windows per launch, device workspace bytes per batch).  Results never depend on them. */
 void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
                       uint64_t max_workspace_bytes);
+/* Work per lane of the two bucket kernels, as log2 (0, the default, lets every launch choose from
+ * its size): sorted entries per accumulation lane (2^3..2^10; 32 for a single column so that its
+ * lanes fill the machine, up to 128 when hundreds of columns do -- every segment leaves one partial
+ * sum to fold) and buckets per bucket-reduction lane (2^1..2^8; 8 for a single column: shortest
+ * dependent chain, up to 64 for many: least total work).  Results never depend on them. */
+void bzamd_set_segments(uint32_t log2_entries_per_accumulate_lane,
+                        uint32_t log2_buckets_per_reduce_lane);
 
 /* Per-stage device timing of the next `max_calls` MSM calls issued on the current device, measured
  * with HIP events on the launch stream.  `bzamd_stage_timing_collect` blocks until those calls

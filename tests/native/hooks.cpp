@@ -170,7 +170,7 @@ int bz_recode_words32(int* digits, const u8* row, u32 skew, u32 bit_offset, u32 
 
 // planner (msm/plan.h): per column {window_bits, num_windows, slices, first_task, slice_rows,
 // group_bits}; totals {tasks, total_buckets, total_entries, total_segments, rows covered,
-// total_groups}
+// total_groups, log2 entries per accumulate lane, log2 buckets per reduce lane}
 void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, const int* is_signed,
              u32 num_columns, u32 max_window_bits) {
   std::vector<host_column> cols(num_columns);
@@ -197,6 +197,8 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
   for (const auto& t : plan.tasks) covered += t.rows;
   totals[4] = covered;
   totals[5] = plan.total_groups;
+  totals[6] = plan.segment_log2;
+  totals[7] = plan.reduce_segment_log2;
 }
 
 // planner with a window table (msm/plan.h `window_table`): per column {window_bits, num_windows,

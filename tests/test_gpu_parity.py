@@ -299,8 +299,15 @@ def test_skewed_and_batched_columns(gpu_backend, oracle):
         assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
         lib.bzamd_set_tuning(16, 32768, 1 << 20)  # 1 MiB of workspace: one column per batch
         assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
+        # bucket reduction geometry: 2 .. 64 buckets per lane (one partial per 512 .. 16384 buckets)
+        lib.bzamd_set_tuning(16, 32768, 64 << 30)
+        # and 8 .. 128 sorted entries per accumulation lane
+        for acc_log2, red_log2 in ((0, 1), (3, 4), (6, 6), (7, 0)):
+            lib.bzamd_set_segments(acc_log2, red_log2)
+            assert np.array_equal(api.compute_pedersen_commitments(0, cols, generators=g), want)
     finally:
         lib.bzamd_set_tuning(16, 32768, 64 << 30)
+        lib.bzamd_set_segments(0, 0)
 
 
 def test_skewed_long_column(gpu_backend):

@@ -155,6 +155,8 @@ def test_planner_invariants():
     widths = [256, 8, 32, 256, 64, 16, 256, 1, 256, 256, 128]
     per, totals = hooks.plan(ns, widths, [0] * len(ns))
     assert per[0].tolist()[:3] == [1, 0, 0]  # empty column: no tasks
+    seg = 1 << int(totals[6])  # sorted entries per accumulation lane, one value per launch
+    assert seg == 128          # a launch with this many entries takes the longest segments
     covered = tasks = segs = part = 0
     for n, bw, (c, W, slices, first, slice_rows, s) in zip(ns, widths, per.tolist()):
         if n == 0:
@@ -169,13 +171,23 @@ def test_planner_invariants():
         groups = 1 << (c - 1 - s)
         covered += W * n
         tasks += W
-        segs += W * ((n + 31) // 32)
+        segs += W * ((n + seg - 1) // seg)
         part += W * (groups + 1)
     assert int(totals[0]) == tasks and int(totals[4]) == covered
     assert int(totals[3]) == segs and int(totals[5]) == part
     # config 2 / config 3 shapes: groups of ~4096 entries, slices staged in LDS
-    per, _ = hooks.plan([1 << 20, 1 << 22], [256, 256], [0, 0])
+    per, totals = hooks.plan([1 << 20, 1 << 22], [256, 256], [0, 0])
     assert per[0].tolist()[4:] == [16384, 7] and per[1].tolist()[4:] == [16384, 5]
+    # work per lane of the bucket kernels: a single column is latency-bound (32 entries per
+    # accumulation lane so that its lanes fill the machine, 8 buckets per reduce lane: shortest
+    # chain); 256 columns are throughput-bound (128 entries, 64 buckets: least total work) and
+    # price a bucket at its throughput cost, which still leaves c = 16 for 2^20 rows
+    assert totals[6:].tolist() == [5, 3]
+    per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256)
+    assert totals[6:].tolist() == [7, 6] and per[0][0] == 16
+    # blocks of the bucket reduction stay full: 2^13 buckets per task leave 32 per lane
+    per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256, max_window_bits=14)
+    assert per[0][0] == 14 and totals[6:].tolist() == [7, 5]
     # signed columns are planned with c <= 15 by the engine (digits must fit int16 negated)
     per, _ = hooks.plan([1 << 20], [128], [1], max_window_bits=15)
     assert per[0][0] <= 15
