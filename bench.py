@@ -41,11 +41,11 @@ import baseline_workloads as wl  # noqa: E402
 STAGES = ["prepare_addends", "recode", "bucket_sort", "accumulate", "reduce", "combine"]
 HBM_PEAK_GBS = 8000.0
 # integer-ALU side of k_accumulate (the honest binding bound).  v_mad_u64_u32 per
-# bucket addition = the count in the kernel's ISA (field products x 92: 81 limb products, 9
-# wrap-arounds, 2 folds).  Peak: the instruction issues once per 4 shader cycles per SIMD
+# bucket addition = the count in the kernel's ISA (field products x 99: 81 limb products, 16 that
+# fold the eight high columns, as 64-bit sums, onto the low ones, 2 for the last carry).  Peak: the instruction issues once per 4 shader cycles per SIMD
 # (profiles/round2_valu_rates.txt: 4.5 against the 2.4 of a plain VALU op), 1024 SIMDs; the clock is
 # the effective shader clock the same micro-benchmark measures under an all-SIMD integer load.
-MADS_PER_ADDITION = {"cached": 736, "niels": 644}
+MADS_PER_ADDITION = {"cached": 792, "niels": 693}  # 8 (7) products x (81 + 17 + 1), ISA count
 SIMDS = 1024
 MAD_ISSUE_CYCLES = 4.0
 EFFECTIVE_CLOCK_HZ = 2.1e9  # refined from profiles/alu_calibration.json when present

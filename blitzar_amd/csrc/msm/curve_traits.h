@@ -312,19 +312,26 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
     if (G29::is_identity_addend(q)) return;
     acc = G29::template add_mixed<accumulate_pinned>(acc, G29::unpack(q), negate);
   }
-  // k_accumulate's pipeline (see ed25519_msm::stage)
+  // k_accumulate's pipeline (see ed25519_msm::stage); the identity test is folded to one word here,
+  // so nothing of the packed row is read after this point
   struct operand {
     typename G29::affine a;
-    bool skip; // the identity's all-zero row
+    u32 nonzero; // 0: the identity's all-zero row
   };
   BZ_HD static operand stage(const addend& q) {
-    operand o{G29::unpack(q), G29::is_identity_addend(q)};
+    u64 any = 0;
+#pragma unroll
+    for (int i = 0; i < N64; ++i) any |= q.x[i] | q.y[i];
+    operand o{G29::unpack(q), static_cast<u32>(any) | static_cast<u32>(any >> 32)};
     F29::pin(o.a.x);
     F29::pin(o.a.y);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(o.nonzero));
+#endif
     return o;
   }
   BZ_HD static void accumulate(point& acc, const operand& q, bool negate) {
-    if (q.skip) return;
+    if (q.nonzero == 0) return;
     acc = G29::template add_mixed<accumulate_pinned>(acc, q.a, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {

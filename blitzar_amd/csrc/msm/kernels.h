@@ -988,8 +988,12 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
     next_end = ends[b < last_bucket ? b + 1 : last_bucket];
     const typename C::operand q = C::stage(staged);
     const bool negate = (e_cur >> 31) != 0;
+    // the gather is unconditional (the last iteration re-reads its own row, a cache hit): a load
+    // under `if (i + 1 < hi)` writes its registers in some lanes only, and hipcc then keeps two
+    // copies of the row and moves it back and forth (bn254: 16 v_mov_b64 per iteration)
+    const u32 row = (i + 1 < hi ? e_next : e_cur) & 0x7fffffffu;
     e_cur = e_next;
-    if (i + 1 < hi) staged = addends[e_cur & 0x7fffffffu];
+    staged = addends[row];
     if (i + 2 < hi) e_next = idx[i + 2];
     C::accumulate(acc, q, negate);
   }

@@ -182,7 +182,10 @@ def test_planner_invariants():
     # accumulation lane so that its lanes fill the machine, 8 buckets per reduce lane: shortest
     # chain); 256 columns are throughput-bound (128 entries, 64 buckets: least total work) and
     # price a bucket at its throughput cost, which still leaves c = 16 for 2^20 rows
+    _, totals = hooks.plan([1 << 20], [256], [0])
     assert totals[6:].tolist() == [5, 3]
+    _, totals = hooks.plan([1 << 22], [256], [0])
+    assert totals[6:].tolist() == [7, 3]
     per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256)
     assert totals[6:].tolist() == [7, 6] and per[0][0] == 16
     # blocks of the bucket reduction stay full: 2^13 buckets per task leave 32 per lane
