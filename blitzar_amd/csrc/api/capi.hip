@@ -1038,6 +1038,12 @@ void bzamd_stage_timing_begin(uint64_t max_calls) {
   msm_context_timing_begin(st.context_for_current_device(), max_calls);
 }
 
+void bzamd_stage_timing_begin_masked(uint64_t max_calls, uint32_t stage_mask) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "stage timing needs the GPU backend");
+  msm_context_timing_begin(st.context_for_current_device(), max_calls, stage_mask);
+}
+
 uint64_t bzamd_stage_timing_collect(double* out_ms) {
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "stage timing needs the GPU backend");

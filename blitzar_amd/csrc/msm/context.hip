@@ -76,9 +76,9 @@ void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_
   ctx->tuning.force_segment_log2 = log2_entries_per_accumulate_lane;
   ctx->tuning.force_reduce_segment_log2 = log2_buckets_per_reduce_lane;
 }
-void msm_context_timing_begin(msm_context* ctx, size_t max_calls) {
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask) {
   std::lock_guard<std::mutex> lock(ctx->mu);
-  ctx->timer.begin(max_calls);
+  ctx->timer.begin(max_calls, stage_mask & 0x3f);
 }
 size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]) {
   std::lock_guard<std::mutex> lock(ctx->mu);

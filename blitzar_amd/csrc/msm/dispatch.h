@@ -89,7 +89,8 @@ void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_ta
 void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_lane,
                               u32 log2_buckets_per_reduce_lane);
 // per-stage HIP-event timing of the next `max_calls` MSM calls on this context
-void msm_context_timing_begin(msm_context* ctx, size_t max_calls);
+// (`stage_mask`: bit s set = record stage s; every recorded stage costs an event pair per call)
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask = 0x3f);
 // accumulated ms per stage {prepare, recode, sort, accumulate, reduce, combine}; returns #calls
 size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]);
 } // namespace bz

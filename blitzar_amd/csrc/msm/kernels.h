@@ -176,7 +176,14 @@ void launch_prepare_addends(typename C::addend* d_addends, const void* d_api_gen
 // lane touches its own cache line and the neighbouring columns find it in that XCD's L2.
 static __global__ void __launch_bounds__(256)
     k_recode(i16* __restrict__ digits, const column_desc* __restrict__ columns,
-             const task_desc* __restrict__ tasks, u32 num_columns, u32 num_chunks) {
+             const task_desc* __restrict__ tasks, u32 num_columns, u32 num_chunks,
+             u32* __restrict__ zero, u64 zero_words) {
+  // the group cursors of the sort start at zero: cleared here, by the first kernel of the call,
+  // instead of by a memset (two fill kernels and two stream bubbles per call)
+  for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < zero_words;
+       i += static_cast<u64>(gridDim.x) * blockDim.x) {
+    zero[i] = 0;
+  }
   const u64 chunk_groups = (num_chunks + 7) / 8;
   const u64 total = 8 * chunk_groups * num_columns;
   for (u64 id = blockIdx.x; id < total; id += gridDim.x) {
@@ -224,7 +231,12 @@ static __global__ void __launch_bounds__(256)
 static __global__ void __launch_bounds__(kPackedRecodeThreads)
     k_recode_packed(i16* __restrict__ digits, const column_desc* __restrict__ columns,
                     const task_desc* __restrict__ tasks, const recode_range* __restrict__ ranges,
-                    u32 num_ranges, u64 row_stride, u64 max_rows, u64 data_rows) {
+                    u32 num_ranges, u64 row_stride, u64 max_rows, u64 data_rows,
+                    u32* __restrict__ zero, u64 zero_words) {
+  for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < zero_words;
+       i += static_cast<u64>(gridDim.x) * blockDim.x) {
+    zero[i] = 0; // the sort's group cursors (see k_recode)
+  }
   extern __shared__ __attribute__((aligned(16))) u8 tile[];
   __shared__ u32 row_shift[kPackedTileRows];
   const u64 row0 = static_cast<u64>(blockIdx.x) * kPackedTileRows;

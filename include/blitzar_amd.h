@@ -72,8 +72,11 @@ void bzamd_set_segments(uint32_t log2_entries_per_accumulate_lane,
  * with HIP events on the launch stream.  `bzamd_stage_timing_collect` blocks until those calls
  * finished, writes the accumulated milliseconds of the six stages
  * {prepare_addends, recode, bucket_sort, accumulate, reduce, combine} to out_ms[6] and returns the
- * number of calls recorded. */
+ * number of calls recorded.  Every recorded stage puts an event pair on the stream, i.e. two bubbles
+ * of a few microseconds per call: `_masked` records only the stages whose bit is set in
+ * `stage_mask` (bit 3 = accumulate), the others read 0. */
 void bzamd_stage_timing_begin(uint64_t max_calls);
+void bzamd_stage_timing_begin_masked(uint64_t max_calls, uint32_t stage_mask);
 uint64_t bzamd_stage_timing_collect(double* out_ms);
 
 /* Variable-base MSM on device-resident operands.
