@@ -128,14 +128,19 @@ class StageClock:
         return per_call, batches
 
 
-def timed_calls(lib, fn, steps, warmup):
+def timed_calls(lib, fn, steps, warmup, stream):
+    """seconds per call of a sequence of `steps` calls in the library's throughput mode (the last
+    stage of a call beside the front of the next, bzamd_pipeline_next), flushed inside the timed
+    region; stage times from the same calls"""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     clock = StageClock(lib, steps * 64)
     t0 = time.perf_counter()
     for _ in range(steps):
+        lib.bzamd_pipeline_next()
         fn()
+    lib.bzamd_pipeline_flush(stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     stages, _ = clock.collect(steps)
@@ -202,7 +207,7 @@ def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps,
     def step():
         lib.bzamd_msm_device(cid, vp(out), columns, desc, vp(gens), stream)
 
-    dt, stages = timed_calls(lib, step, steps, 1)
+    dt, stages = timed_calls(lib, step, steps, 1, stream)
     got = out.cpu().numpy()
     bad = []
     for c in range(columns):
@@ -261,7 +266,7 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
             vp(res), handle._h, bit_table.ctypes.data_as(ctypes.c_void_p), None, outputs, n,
             vp(scalars), stream)
 
-    dt, stages = timed_calls(lib, step, steps, 1)
+    dt, stages = timed_calls(lib, step, steps, 1, stream)
     got = res.cpu().numpy()
     sums = wl.weighted_byte_sums(scalars)
     bad = []
@@ -426,13 +431,29 @@ def main():
     desc[0] = api.sxt_sequence_descriptor(nbytes, n, scalars.data_ptr(), 0)
     torch.cuda.synchronize()
 
-    def step():
-        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
-        if world > 1:
-            coll.all_gather(gathered, out)
+    # The steps run in the library's throughput mode (bzamd_pipeline_next, include/blitzar_amd.h):
+    # the last stage of step k -- one workgroup walking the column's chain of doublings -- runs on
+    # the engine's tail stream beside the generator conversion, recoding and sorting of step k + 1.
+    # A step's commitment is complete on the stream once the next step has been enqueued, so the
+    # all-gather of step k carries the commitment of step k - 1 (two output buffers), and a flush
+    # plus the last gather close the sequence inside the timed region: K MSMs, K gathers.
+    outs = [out, torch.zeros_like(out)]
 
-    for _ in range(args.warmup):
-        step()
+    def step(k):
+        lib.bzamd_pipeline_next()
+        lib.bzamd_msm_device(curve_id, vp(outs[k & 1]), 1, desc, vp(generators), stream)
+        if world > 1 and k > 0:
+            coll.all_gather(gathered, outs[(k - 1) & 1])
+
+    def finish(k_last):
+        lib.bzamd_pipeline_flush(stream)
+        if world > 1:
+            coll.all_gather(gathered, outs[k_last & 1])
+
+    for k in range(args.warmup):
+        step(k)
+    if args.warmup:
+        finish(args.warmup - 1)
     torch.cuda.synchronize()
     if world > 1:
         coll.barrier()
@@ -442,15 +463,19 @@ def main():
     # other five stages are measured by a separate, untimed pass below
     clock = StageClock(lib, args.steps, ACCUMULATE_ONLY)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
+    finish(args.steps - 1)
     torch.cuda.synchronize()
     if world > 1:
         coll.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed_stages, calls = clock.collect(args.steps)
-    timed_output = out.cpu().numpy().copy()
+    timed_output = outs[(args.steps - 1) & 1].cpu().numpy().copy()
+    if world > 1:
+        assert np.array_equal(gathered.cpu().numpy()[rank], timed_output[0])
+    # untimed passes: the six stage times, and the latency of a lone call (no throughput mode)
     stage_steps = min(args.steps, 50)
     clock = StageClock(lib, stage_steps)
     for _ in range(stage_steps):
@@ -458,6 +483,12 @@ def main():
     torch.cuda.synchronize()
     per_call, _ = clock.collect(stage_steps)
     per_call["accumulate"] = timed_stages["accumulate"]
+    t_single = time.perf_counter()
+    for _ in range(stage_steps):
+        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
+    torch.cuda.synchronize()
+    single_call_ms = 1e3 * (time.perf_counter() - t_single) / stage_steps
+    assert np.array_equal(out.cpu().numpy(), timed_output), "lone call disagrees with the sequence"
 
     # informational second leg (single-GPU run): the same step with the generators registered once
     # as a resident set (bzamd_generators_*).  Never used for `value`.
@@ -471,7 +502,9 @@ def main():
         clock2 = StageClock(lib, args.steps, ACCUMULATE_ONLY)
         t1 = time.perf_counter()
         for _ in range(args.steps):
+            lib.bzamd_pipeline_next()
             lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+        lib.bzamd_pipeline_flush(stream)
         torch.cuda.synchronize()
         resident_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         resident_acc, _ = clock2.collect(args.steps)
@@ -525,6 +558,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "single_call_ms": single_call_ms,
+            "mode": "throughput mode of the library (bzamd_pipeline_next / bzamd_pipeline_flush): the "
+                    "last stage of step k (one workgroup per column) runs beside the front of step "
+                    "k + 1; all K commitments are complete, and the last one verified, inside the "
+                    "timed region; `single_call_ms` = a lone call with plain stream semantics",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -96,6 +96,10 @@ def load():
     lib.bzamd_set_segments.restype = None
     lib.bzamd_stage_timing_begin.argtypes = [u64]
     lib.bzamd_stage_timing_begin.restype = None
+    lib.bzamd_pipeline_next.argtypes = []
+    lib.bzamd_pipeline_next.restype = None
+    lib.bzamd_pipeline_flush.argtypes = [ctypes.c_void_p]
+    lib.bzamd_pipeline_flush.restype = None
     lib.bzamd_stage_timing_begin_masked.argtypes = [u64, u32]
     lib.bzamd_stage_timing_begin_masked.restype = None
     lib.bzamd_stage_timing_collect.argtypes = [ctypes.POINTER(ctypes.c_double)]

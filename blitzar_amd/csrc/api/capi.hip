@@ -1090,6 +1090,18 @@ void msm_device(unsigned curve_id, void* out, uint32_t num_sequences,
 }
 } // namespace
 
+void bzamd_pipeline_next(void) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
+  msm_context_defer_next_tail(st.context_for_current_device());
+}
+
+void bzamd_pipeline_flush(void* stream) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
+  msm_context_join_tail(st.context_for_current_device(), static_cast<hipStream_t>(stream));
+}
+
 void bzamd_msm_device(unsigned curve_id, void* commitments, uint32_t num_sequences,
                       const struct sxt_sequence_descriptor* descriptors, const void* generators,
                       void* stream) {

@@ -51,6 +51,8 @@ msm_context* msm_context_new() {
     ctx->tuning.force_window_tables = v[0] != '0';
   }
   if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_PREPARE")) ctx->overlap_prepare = v[0] != '0';
+  if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_TAILS")) ctx->overlap_tails = v[0] != '0';
+
   return ctx;
 }
 void msm_context_free(msm_context* ctx) { delete ctx; }
@@ -75,6 +77,14 @@ void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_
                     "buckets per reduce lane: 2^1 .. 2^8 (0 = automatic)");
   ctx->tuning.force_segment_log2 = log2_entries_per_accumulate_lane;
   ctx->tuning.force_reduce_segment_log2 = log2_buckets_per_reduce_lane;
+}
+void msm_context_defer_next_tail(msm_context* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->defer_tail = true;
+}
+void msm_context_join_tail(msm_context* ctx, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->join_tail(stream);
 }
 void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask) {
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -84,6 +84,10 @@ void msm_context_free(msm_context* ctx);
 // per batch of columns
 void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
                             size_t max_workspace_bytes);
+// throughput mode (bzamd_msm_device_pipelined): the next MSM enqueued on this context leaves its last
+// stage running on the context's tail stream; `join_tail` makes `stream` wait for it
+void msm_context_defer_next_tail(msm_context* ctx);
+void msm_context_join_tail(msm_context* ctx, hipStream_t stream);
 // sorted entries per k_accumulate lane = 2^a (3..10), buckets per k_reduce lane = 2^r (1..8);
 // 0 = chosen per launch from its entry / bucket counts (plan.h)
 void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_lane,

@@ -107,6 +107,36 @@ struct msm_context {
   // copy and the two stream bubbles around it (~15 us of a 1.3 ms call).  Only msm_enqueue_batch
   // writes the block, always on the stream of the call, and calls on one context are ordered
   // (order_after_previous), so the block never changes under a kernel that reads it.
+  // Tail stream: k_horner -- ONE workgroup per column running a dependent chain of ~250 doublings
+  // and the encoding's 250 squarings (0.19 ms at config 2, the machine otherwise idle) -- is
+  // launched on a stream of its own, so that it runs beside whatever the caller's stream does
+  // next on this context: the generator conversion, recoding and sorting of the next batch or
+  // call, which touch nothing k_horner reads (partials, task totals, descriptors).  The caller's
+  // stream joins (`join_tail`) before the next k_reduce overwrites the partials and before changed
+  // descriptors are copied.  Used between the batches of a many-column call, and for the last
+  // batch of a call issued in throughput mode (`defer_tail`: bzamd_msm_device_pipelined, whose
+  // result is complete on the caller's stream only after the next call or a flush); every other
+  // call runs its last k_horner on the caller's stream -- plain stream semantics, and the fork /
+  // join pair would only cost it two stream bubbles (measured: 1.237 -> 1.266 ms at config 2,
+  // against 1.065 ms per call in a deferred sequence).
+  hipStream_t tail = nullptr;
+  hipEvent_t tail_fork = nullptr, tail_done = nullptr;
+  bool tail_pending = false;
+  bool defer_tail = false;    // the next call leaves its tail pending (msm_context_defer_next_tail)
+  bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: k_horner always on the caller's stream
+  hipStream_t tail_stream() {
+    if (tail == nullptr) {
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_fork, hipEventDisableTiming));
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_done, hipEventDisableTiming));
+    }
+    return tail;
+  }
+  void join_tail(hipStream_t stream) {
+    if (!tail_pending) return;
+    BZ_HIP_CHECK(hipStreamWaitEvent(stream, tail_done, 0));
+    tail_pending = false;
+  }
   char* desc_dev = nullptr;
   size_t desc_cap = 0;
   std::vector<char> desc_shadow, desc_image;
@@ -126,6 +156,9 @@ struct msm_context {
     if (join != nullptr) (void)hipEventDestroy(join);
     if (side != nullptr) (void)hipStreamDestroy(side);
     if (desc_dev != nullptr) (void)hipFree(desc_dev);
+    if (tail_fork != nullptr) (void)hipEventDestroy(tail_fork);
+    if (tail_done != nullptr) (void)hipEventDestroy(tail_done);
+    if (tail != nullptr) (void)hipStreamDestroy(tail);
   }
   hipStream_t side_stream() {
     if (side == nullptr) {
@@ -185,6 +218,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   need += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
   need += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
   need += device_arena::padded(sizeof(point) * (num_cols + 1));
+  need += device_arena::padded(sizeof(u32) * (num_tasks + 1));
   return need;
 }
 
@@ -195,7 +229,7 @@ static inline u32 partial_stride_of(const msm_plan& plan) {
 template <class C>
 void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const msm_plan& plan, const typename C::addend* d_addends,
-                       const void* d_api_generators, hipStream_t stream);
+                       const void* d_api_generators, hipStream_t stream, bool tail_on_side);
 
 // Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
 // (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
@@ -211,6 +245,8 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   std::lock_guard<std::mutex> lock(ctx.mu);
   configure_sort_kernels(ctx);
   ctx.order_after_previous(stream);
+  const bool defer_tail = ctx.defer_tail && ctx.overlap_tails;
+  ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   bool any_signed = false;
   for (const auto& c : cols) any_signed = any_signed || c.is_signed;
@@ -267,12 +303,15 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     begin = end;
   }
   // one allocation sized for the largest batch: later resets never reallocate (no mid-call sync)
+  if (need > ctx.arena.capacity()) ctx.join_tail(stream); // the arena is about to be re-allocated
   ctx.arena.reset(need, stream);
   for (size_t k = 0; k < batches.size(); ++k) {
     ctx.arena.reset(need, stream);
     msm_enqueue_batch<C>(ctx, d_out + first_column[k] * static_cast<size_t>(out_stride), out_stride,
-                         projective_out, batches[k], d_addends, d_api_generators, stream);
+                         projective_out, batches[k], d_addends, d_api_generators, stream,
+                         ctx.overlap_tails && (defer_tail || k + 1 < batches.size()));
   }
+  if (!defer_tail) ctx.join_tail(stream);
   ctx.mark_enqueued(stream);
 }
 
@@ -295,13 +334,14 @@ template <class C> struct batch_buffers {
   typename C::point* heads;
   typename C::point* partials;
   typename C::point* horner_state;
+  u32* task_total; // entries per task, written by k_reduce for k_horner
   u32 partial_stride;
 };
 
 template <class C>
 void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const msm_plan& plan, const typename C::addend* d_addends,
-                       const void* d_api_generators, hipStream_t stream) {
+                       const void* d_api_generators, hipStream_t stream, bool tail_on_side) {
   using point = typename C::point;
   using addend = typename C::addend;
   const u32 num_tasks = static_cast<u32>(plan.tasks.size());
@@ -331,6 +371,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   }
   char* desc = ctx.descriptor_block(desc_bytes);
   if (image != ctx.desc_shadow) {
+    ctx.join_tail(stream); // a k_horner still reading the previous descriptors goes first
     char* staged = static_cast<char*>(ctx.descriptors.acquire(desc_bytes));
     std::memcpy(staged, image.data(), desc_bytes);
     BZ_HIP_CHECK(hipMemcpyAsync(desc, staged, desc_bytes, hipMemcpyHostToDevice, stream));
@@ -384,6 +425,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.heads = ctx.arena.take<point>(plan.total_segments + 1);
   b.partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * b.partial_stride + 1);
   b.horner_state = ctx.arena.take<point>(num_cols);
+  b.task_total = ctx.arena.take<u32>(num_tasks + 1);
   const size_t part_lds = sizeof(u32) * plan.max_task_groups;
   const u32 seg_blocks =
       ceil_div_u32(plan.max_task_rows, static_cast<u64>(kAccumulateThreads) << plan.segment_log2);
@@ -448,18 +490,30 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        stream, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
                        b.addends, b.tasks);
   });
+  ctx.join_tail(stream); // the previous k_horner reads the partials k_reduce is about to write
   ctx.timer.timed(timing, 4, stream, [&] {
     hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
-                       stream, b.partials, b.partial_stride, b.bucket_sums, b.heads, b.bucket_end,
-                       b.tasks, plan.reduce_segment_log2);
+                       stream, b.partials, b.partial_stride, b.task_total, b.bucket_sums, b.heads,
+                       b.bucket_end, b.tasks, plan.reduce_segment_log2);
   });
-  // whole columns in one launch: the range covers every window, first and last
-  ctx.timer.timed(timing, 5, stream, [&] {
-    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
-                       out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
-                       b.partial_stride, b.cols, b.tasks, b.bucket_end, 0u, 0xffffffffu, 1, 1,
+  // whole columns in one launch: the range covers every window, first and last; on the tail
+  // stream (msm_context::tail), joined by the caller's stream later
+  hipStream_t horner_stream = stream;
+  if (tail_on_side) {
+    horner_stream = ctx.tail_stream();
+    BZ_HIP_CHECK(hipEventRecord(ctx.tail_fork, stream));
+    BZ_HIP_CHECK(hipStreamWaitEvent(horner_stream, ctx.tail_fork, 0));
+  }
+  ctx.timer.timed(timing, 5, horner_stream, [&] {
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, horner_stream,
+                       d_out, out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
+                       b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
                        plan.reduce_segment_log2);
   });
+  if (tail_on_side) {
+    BZ_HIP_CHECK(hipEventRecord(ctx.tail_done, horner_stream));
+    ctx.tail_pending = true;
+  }
   if (timing) ctx.timer.calls += 1;
   g_kernel_launches += 10;
   BZ_HIP_CHECK(hipGetLastError());

@@ -1127,7 +1127,7 @@ __device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end, u32 seg_log
 template <class C>
 __global__ void __launch_bounds__(kReduceThreads)
     k_reduce(typename C::point* __restrict__ partials, u32 partial_stride,
-             const typename C::point* __restrict__ bucket_sums,
+             u32* __restrict__ task_total, const typename C::point* __restrict__ bucket_sums,
              const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
              const task_desc* __restrict__ tasks, u32 lane_log2) {
   using point = typename C::point;
@@ -1141,6 +1141,8 @@ __global__ void __launch_bounds__(kReduceThreads)
   const u32 tid = threadIdx.x;
   const u32* ends = bucket_end + task.bucket_base;
   const u32 total = ends[nb - 1];
+  // entries of the task, for k_horner (which then reads nothing a following sort overwrites)
+  if (blockIdx.x == 0 && tid == 0) task_total[blockIdx.y] = total;
   point* dst = partials + static_cast<u64>(blockIdx.y) * partial_stride + blockIdx.x;
   if (total == 0) {
     if (tid == 0) *dst = C::identity();
@@ -1285,7 +1287,7 @@ __global__ void __launch_bounds__(kCombineThreads)
     k_horner(u8* __restrict__ out, u32 out_stride, int projective_out,
              typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
              u32 partial_stride, const column_desc* __restrict__ columns,
-             const task_desc* __restrict__ tasks, const u32* __restrict__ bucket_end, u32 w_lo_arg,
+             const task_desc* __restrict__ tasks, const u32* __restrict__ task_total, u32 w_lo_arg,
              u32 w_hi_arg, int first, int last, u32 reduce_seg_log2) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
@@ -1299,8 +1301,7 @@ __global__ void __launch_bounds__(kCombineThreads)
     // windows above the highest populated one contribute nothing: start the chain below them
     // (a 64-bit value in a 32-byte column keeps 4 of its 17 windows: 48 doublings instead of 256)
     while (w_hi > w_lo) {
-      const task_desc& t = tasks[col.first_task + w_hi - 1];
-      if (bucket_end[t.bucket_base + t.num_buckets - 1] != 0) break;
+      if (task_total[col.first_task + w_hi - 1] != 0) break;
       --w_hi;
     }
   }

@@ -394,6 +394,64 @@ def test_device_resident_entry_points(gpu_backend, oracle):
             lib.bzamd_generators_free(h)
 
 
+def test_pipelined_calls(gpu_backend, oracle):
+    """bzamd_pipeline_next / bzamd_pipeline_flush (include/blitzar_amd.h): a sequence of calls whose
+    last stage runs on the engine's tail stream beside the front of the next call.  Calls with the
+    same descriptors (the fast path: nothing is re-uploaded), with different ones (the engine joins
+    before it overwrites what the pending stage reads), on two curves and through the resident
+    entry point; every output buffer is read after the NEXT call was enqueued or after a flush."""
+    import ctypes
+    import torch
+    api = gpu_backend
+    lib = api.load()
+    dev = torch.device("cuda", 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(33)
+    jobs = []
+    for curve_id, n in ((0, 40000), (2, 2500)):
+        gens = util.generators_for(curve_id, n)
+        g_host = np.ascontiguousarray(util.api_generators(curve_id, gens))
+        d_gens = torch.from_numpy(g_host.copy()).to(dev)
+        for rows, nbytes in ((n, 32), (n - 11, 32), (n, 5)):
+            col = rng.integers(0, 256, (rows, nbytes), dtype=np.uint8)
+            want = oracle.commit(curve_id, [(col, False)], gens)
+            d_col = torch.from_numpy(col.copy()).to(dev)
+            desc = (api.sxt_sequence_descriptor * 1)()
+            desc[0] = api.sxt_sequence_descriptor(nbytes, rows, d_col.data_ptr(), 0)
+            jobs.append((curve_id, d_gens, d_col, desc, want))
+    # every job three times in a row (identical descriptors), jobs interleaved (changing ones)
+    order = [j for j in range(len(jobs)) for _ in range(3)] + list(range(len(jobs))) * 2
+    outs, copies = [], []
+    for j in order:
+        curve_id, d_gens, _, desc, want = jobs[j]
+        out = torch.zeros((1, want.shape[1]), dtype=torch.uint8, device=dev)
+        lib.bzamd_pipeline_next()
+        lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, desc,
+                             ctypes.c_void_p(d_gens.data_ptr()), stream)
+        if outs:  # the previous call is complete on the stream now: copy it out, stream-ordered
+            copies.append((outs[-1][0], outs[-1][1].clone()))
+        outs.append((j, out))
+    lib.bzamd_pipeline_flush(stream)
+    copies.append((outs[-1][0], outs[-1][1].clone()))
+    torch.cuda.synchronize()
+    assert len(copies) == len(order)
+    for j, got in copies:
+        assert np.array_equal(got.cpu().numpy(), jobs[j][4]), f"pipelined job {j}"
+    # a plain call after a pipelined one needs no flush of its own
+    curve_id, d_gens, _, desc, want = jobs[0]
+    h = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(d_gens.data_ptr()), 40000, stream)
+    a = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+    b = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+    lib.bzamd_pipeline_next()
+    lib.bzamd_msm_device_resident(ctypes.c_void_p(a.data_ptr()), 1, desc, h, stream)
+    lib.bzamd_msm_device(curve_id, ctypes.c_void_p(b.data_ptr()), 1, desc,
+                         ctypes.c_void_p(d_gens.data_ptr()), stream)
+    got_a, got_b = a.clone(), b.clone()
+    torch.cuda.synchronize()
+    assert np.array_equal(got_a.cpu().numpy(), want) and np.array_equal(got_b.cpu().numpy(), want)
+    lib.bzamd_generators_free(h)
+
+
 @pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
 def test_random_sweep_matches_oracle(gpu_backend, oracle, curve_id):
     """the randomized part of the reference exerciser (sxt/multiexp/test/multiexponentiation.cc:
