@@ -107,35 +107,50 @@ struct msm_context {
   // copy and the two stream bubbles around it (~15 us of a 1.3 ms call).  Only msm_enqueue_batch
   // writes the block, always on the stream of the call, and calls on one context are ordered
   // (order_after_previous), so the block never changes under a kernel that reads it.
-  // Tail stream: k_horner -- ONE workgroup per column running a dependent chain of ~250 doublings
-  // and the encoding's 250 squarings (0.19 ms at config 2, the machine otherwise idle) -- is
-  // launched on a stream of its own, so that it runs beside whatever the caller's stream does
-  // next on this context: the generator conversion, recoding and sorting of the next batch or
-  // call, which touch nothing k_horner reads (partials, task totals, descriptors).  The caller's
-  // stream joins (`join_tail`) before the next k_reduce overwrites the partials and before changed
-  // descriptors are copied.  Used between the batches of a many-column call, and for the last
-  // batch of a call issued in throughput mode (`defer_tail`: bzamd_msm_device_pipelined, whose
-  // result is complete on the caller's stream only after the next call or a flush); every other
-  // call runs its last k_horner on the caller's stream -- plain stream semantics, and the fork /
-  // join pair would only cost it two stream bubbles (measured: 1.237 -> 1.266 ms at config 2,
-  // against 1.065 ms per call in a deferred sequence).
+  // Tail stream.  The two stages after k_accumulate are latency chains that leave the machine
+  // nearly idle: k_reduce runs one wavefront per SIMD, k_horner ONE workgroup per column (~250
+  // dependent doublings and the encoding's 250 squarings); together 0.39 of a 1.24 ms call at
+  // config 2.  In throughput mode they are enqueued on a stream of their own and run beside
+  // whatever the caller's stream does next on this context: the generator conversion, recoding
+  // and sorting of the next batch or call, and the start of its accumulation.  What the tail reads
+  // and the next front writes -- bucket ends, bucket sums, head partials, partials, task totals --
+  // then exists twice, and consecutive calls alternate (`tail_parity`); a call waits for the tail
+  // that used its set two calls ago (`tail_done[parity]`) before its sort rewrites the bucket ends.
+  // That only works while consecutive calls carve the arena identically (same descriptors, same
+  // curve, same mode: `tail_layout`); any other call first joins every pending tail (`join_tail`),
+  // and so does a changed descriptor block, a re-allocation of the arena, the end of a call that is
+  // not deferred, and bzamd_pipeline_flush.  Used across calls issued through bzamd_pipeline_next
+  // (whose results are complete on the caller's stream only after a later call or a flush); any
+  // other call keeps everything on the caller's stream -- plain stream semantics, and forking
+  // would only add stream bubbles (measured: 1.237 -> 1.266 ms at config 2).  The tail kernels
+  // raise their wave priority (s_setprio): beside a k_accumulate that owns every SIMD they would
+  // otherwise crawl (config 3: k_horner 1.3 -> 6.7 ms) and become the pipeline's bottleneck.
   hipStream_t tail = nullptr;
-  hipEvent_t tail_fork = nullptr, tail_done = nullptr;
-  bool tail_pending = false;
+  hipEvent_t tail_fork = nullptr;
+  hipEvent_t tail_done[2] = {nullptr, nullptr};
+  bool tail_pending[2] = {false, false};
+  u32 tail_parity = 0;
+  u64 tail_layout = 0;        // layout tag of the calls whose tails are pending
   bool defer_tail = false;    // the next call leaves its tail pending (msm_context_defer_next_tail)
-  bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: k_horner always on the caller's stream
+  bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: never fork
+  bool tail_includes_reduce = true; // BLITZAR_AMD_TAIL_REDUCE=0: only k_horner forks
   hipStream_t tail_stream() {
     if (tail == nullptr) {
       BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
       BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_fork, hipEventDisableTiming));
-      BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_done, hipEventDisableTiming));
+      for (auto& e : tail_done) BZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     return tail;
   }
+  bool any_tail_pending() const { return tail_pending[0] || tail_pending[1]; }
+  void join_tail(hipStream_t stream, u32 parity) {
+    if (!tail_pending[parity]) return;
+    BZ_HIP_CHECK(hipStreamWaitEvent(stream, tail_done[parity], 0));
+    tail_pending[parity] = false;
+  }
   void join_tail(hipStream_t stream) {
-    if (!tail_pending) return;
-    BZ_HIP_CHECK(hipStreamWaitEvent(stream, tail_done, 0));
-    tail_pending = false;
+    join_tail(stream, 0);
+    join_tail(stream, 1);
   }
   char* desc_dev = nullptr;
   size_t desc_cap = 0;
@@ -157,7 +172,9 @@ struct msm_context {
     if (side != nullptr) (void)hipStreamDestroy(side);
     if (desc_dev != nullptr) (void)hipFree(desc_dev);
     if (tail_fork != nullptr) (void)hipEventDestroy(tail_fork);
-    if (tail_done != nullptr) (void)hipEventDestroy(tail_done);
+    for (auto& e : tail_done) {
+      if (e != nullptr) (void)hipEventDestroy(e);
+    }
     if (tail != nullptr) (void)hipStreamDestroy(tail);
   }
   hipStream_t side_stream() {
@@ -200,7 +217,8 @@ static void configure_sort_kernels(msm_context& ctx) {
 
 // device workspace of one batch of columns (everything carved from the arena)
 template <class C>
-size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial_stride) {
+size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial_stride,
+                           bool two_tail_sets = false) {
   using point = typename C::point;
   using addend = typename C::addend;
   const size_t num_tasks = plan.tasks.size(), num_cols = plan.columns.size();
@@ -213,13 +231,15 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   need += device_arena::padded(sizeof(u32) * (num_tasks + 1));
   need += device_arena::padded(sizeof(u32) * 2 * (plan.total_buckets + 1));
   need += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
-  need += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
-  need += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
-  need += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
-  need += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
-  need += device_arena::padded(sizeof(point) * (num_cols + 1));
-  need += device_arena::padded(sizeof(u32) * (num_tasks + 1));
-  return need;
+  // what the tail stages read (msm_context::tail): twice in throughput mode
+  size_t tail = 0;
+  tail += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
+  tail += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
+  tail += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
+  tail += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
+  tail += device_arena::padded(sizeof(point) * (num_cols + 1));
+  tail += device_arena::padded(sizeof(u32) * (num_tasks + 1));
+  return need + (two_tail_sets ? 2 : 1) * tail;
 }
 
 static inline u32 partial_stride_of(const msm_plan& plan) {
@@ -245,7 +265,13 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   std::lock_guard<std::mutex> lock(ctx.mu);
   configure_sort_kernels(ctx);
   ctx.order_after_previous(stream);
-  const bool defer_tail = ctx.defer_tail && ctx.overlap_tails;
+  // throughput mode is for latency-bound tails: with many columns k_reduce and k_horner fill the
+  // machine themselves (measured, config 4: 352.5 against 348.0 ms with the fork and the second
+  // set of tail buffers), so such a call ignores the request and completes on the caller's stream
+  size_t nonempty_columns = 0;
+  for (const auto& c : cols) nonempty_columns += c.n != 0 ? 1 : 0;
+  const bool defer_tail = ctx.defer_tail && ctx.overlap_tails &&
+                          nonempty_columns < ctx.tuning.throughput_columns;
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   bool any_signed = false;
@@ -265,10 +291,11 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   std::vector<size_t> first_column;
   size_t need = 0;
   const bool needs_addends = d_addends == nullptr;
+  bool two_tail_sets = false;
   auto plan_range = [&](size_t begin, size_t end, size_t& bytes) {
     msm_plan p = make_msm_plan(std::vector<host_column>(cols.begin() + begin, cols.begin() + end),
                                tune, tables);
-    bytes = msm_workspace_bytes<C>(p, needs_addends, partial_stride_of(p));
+    bytes = msm_workspace_bytes<C>(p, needs_addends, partial_stride_of(p), two_tail_sets);
     return p;
   };
   auto fits = [&](const msm_plan& p, size_t bytes) {
@@ -276,32 +303,42 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     return p.tasks.size() <= tune.max_tasks_per_batch && p.columns.size() <= 32768 &&
            bytes <= tune.max_workspace_bytes;
   };
-  for (size_t begin = 0; begin < cols.size();) {
-    size_t bytes = 0;
-    size_t end = cols.size();
-    msm_plan plan = plan_range(begin, end, bytes);
-    if (!fits(plan, bytes) && end - begin > 1) {
-      size_t lo = begin + 1, hi = end; // [begin, lo) is accepted, [begin, hi) is known not to fit
-      plan = plan_range(begin, lo, bytes);
-      while (hi - lo > 1) {
-        const size_t mid = lo + (hi - lo) / 2;
-        size_t mid_bytes = 0;
-        msm_plan p = plan_range(begin, mid, mid_bytes);
-        if (fits(p, mid_bytes)) {
-          plan = std::move(p);
-          bytes = mid_bytes;
-          lo = mid;
-        } else {
-          hi = mid;
+  auto cut_batches = [&] {
+    batches.clear();
+    first_column.clear();
+    need = 0;
+    for (size_t begin = 0; begin < cols.size();) {
+      size_t bytes = 0;
+      size_t end = cols.size();
+      msm_plan plan = plan_range(begin, end, bytes);
+      if (!fits(plan, bytes) && end - begin > 1) {
+        size_t lo = begin + 1, hi = end; // [begin, lo) is accepted, [begin, hi) is known not to fit
+        plan = plan_range(begin, lo, bytes);
+        while (hi - lo > 1) {
+          const size_t mid = lo + (hi - lo) / 2;
+          size_t mid_bytes = 0;
+          msm_plan p = plan_range(begin, mid, mid_bytes);
+          if (fits(p, mid_bytes)) {
+            plan = std::move(p);
+            bytes = mid_bytes;
+            lo = mid;
+          } else {
+            hi = mid;
+          }
         }
+        end = lo;
       }
-      end = lo;
+      if (bytes > need) need = bytes;
+      first_column.push_back(begin);
+      batches.push_back(std::move(plan));
+      begin = end;
     }
-    if (bytes > need) need = bytes;
-    first_column.push_back(begin);
-    batches.push_back(std::move(plan));
-    begin = end;
-  }
+  };
+  // a deferred call runs its tail stages beside the front of the next call (msm_context::tail);
+  // that mode keeps two sets of the tail's buffers
+  two_tail_sets = defer_tail;
+  cut_batches();
+  const bool tail_on_side = two_tail_sets;
   // one allocation sized for the largest batch: later resets never reallocate (no mid-call sync)
   if (need > ctx.arena.capacity()) ctx.join_tail(stream); // the arena is about to be re-allocated
   ctx.arena.reset(need, stream);
@@ -309,7 +346,7 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     ctx.arena.reset(need, stream);
     msm_enqueue_batch<C>(ctx, d_out + first_column[k] * static_cast<size_t>(out_stride), out_stride,
                          projective_out, batches[k], d_addends, d_api_generators, stream,
-                         ctx.overlap_tails && (defer_tail || k + 1 < batches.size()));
+                         tail_on_side);
   }
   if (!defer_tail) ctx.join_tail(stream);
   ctx.mark_enqueued(stream);
@@ -369,9 +406,17 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     std::memcpy(image.data() + col_bytes + task_bytes, ranges.data(),
                 sizeof(recode_range) * ranges.size());
   }
+  // pending tails share descriptors and arena layout with this batch, or they go first
+  const u64 layout = (static_cast<u64>(msm_workspace_bytes<C>(plan, d_addends == nullptr,
+                                                               b.partial_stride, tail_on_side))
+                      << 8) ^
+                     (static_cast<u64>(C::curve_id) << 4) ^ (d_addends == nullptr ? 2u : 0u) ^
+                     (tail_on_side ? 1u : 0u);
+  if (ctx.any_tail_pending() && (layout != ctx.tail_layout || image != ctx.desc_shadow)) {
+    ctx.join_tail(stream);
+  }
   char* desc = ctx.descriptor_block(desc_bytes);
   if (image != ctx.desc_shadow) {
-    ctx.join_tail(stream); // a k_horner still reading the previous descriptors goes first
     char* staged = static_cast<char*>(ctx.descriptors.acquire(desc_bytes));
     std::memcpy(staged, image.data(), desc_bytes);
     BZ_HIP_CHECK(hipMemcpyAsync(desc, staged, desc_bytes, hipMemcpyHostToDevice, stream));
@@ -420,12 +465,24 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.big_tasks = ctx.arena.take<u32>(num_tasks + 1);
   b.bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
   b.segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
-  b.bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
-  b.bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
-  b.heads = ctx.arena.take<point>(plan.total_segments + 1);
-  b.partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * b.partial_stride + 1);
-  b.horner_state = ctx.arena.take<point>(num_cols);
-  b.task_total = ctx.arena.take<u32>(num_tasks + 1);
+  // what the tail stages read: two sets in throughput mode, this batch uses set `parity`
+  const u32 parity = tail_on_side ? ctx.tail_parity : 0;
+  for (u32 set = 0; set < (tail_on_side ? 2u : 1u); ++set) {
+    u32* bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
+    point* bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
+    point* heads = ctx.arena.take<point>(plan.total_segments + 1);
+    point* partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * b.partial_stride + 1);
+    point* horner_state = ctx.arena.take<point>(num_cols);
+    u32* task_total = ctx.arena.take<u32>(num_tasks + 1);
+    if (set == parity) {
+      b.bucket_end = bucket_end;
+      b.bucket_sums = bucket_sums;
+      b.heads = heads;
+      b.partials = partials;
+      b.horner_state = horner_state;
+      b.task_total = task_total;
+    }
+  }
   const size_t part_lds = sizeof(u32) * plan.max_task_groups;
   const u32 seg_blocks =
       ceil_div_u32(plan.max_task_rows, static_cast<u64>(kAccumulateThreads) << plan.segment_log2);
@@ -455,6 +512,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, stream, b.digits, b.cols,
                        b.tasks, num_cols, chunks, b.group_cursor, zero_words);
   });
+  ctx.join_tail(stream, parity); // (joined at the end of the previous batch already)
   ctx.timer.timed(timing, 2, stream, [&] {
     hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
                        part_lds, stream, b.group_cursor, b.big_tasks, b.digits, b.tasks);
@@ -490,29 +548,37 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        stream, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
                        b.addends, b.tasks);
   });
-  ctx.join_tail(stream); // the previous k_horner reads the partials k_reduce is about to write
-  ctx.timer.timed(timing, 4, stream, [&] {
-    hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
-                       stream, b.partials, b.partial_stride, b.task_total, b.bucket_sums, b.heads,
-                       b.bucket_end, b.tasks, plan.reduce_segment_log2);
-  });
-  // whole columns in one launch: the range covers every window, first and last; on the tail
-  // stream (msm_context::tail), joined by the caller's stream later
-  hipStream_t horner_stream = stream;
-  if (tail_on_side) {
-    horner_stream = ctx.tail_stream();
+  // bucket reduction, then whole columns in one k_horner launch (the range covers every window,
+  // first and last): on the caller's stream, or forked onto the tail stream (msm_context::tail)
+  hipStream_t tail_stream = stream;
+  auto fork = [&] {
+    if (!tail_on_side) return;
+    tail_stream = ctx.tail_stream();
     BZ_HIP_CHECK(hipEventRecord(ctx.tail_fork, stream));
-    BZ_HIP_CHECK(hipStreamWaitEvent(horner_stream, ctx.tail_fork, 0));
-  }
-  ctx.timer.timed(timing, 5, horner_stream, [&] {
-    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, horner_stream,
-                       d_out, out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
+    BZ_HIP_CHECK(hipStreamWaitEvent(tail_stream, ctx.tail_fork, 0));
+  };
+  if (ctx.tail_includes_reduce) fork();
+  ctx.timer.timed(timing, 4, tail_stream, [&] {
+    hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
+                       tail_stream, b.partials, b.partial_stride, b.task_total, b.bucket_sums,
+                       b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
+  });
+  if (!ctx.tail_includes_reduce) fork();
+  ctx.timer.timed(timing, 5, tail_stream, [&] {
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, tail_stream, d_out,
+                       out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
                        b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
                        plan.reduce_segment_log2);
   });
   if (tail_on_side) {
-    BZ_HIP_CHECK(hipEventRecord(ctx.tail_done, horner_stream));
-    ctx.tail_pending = true;
+    BZ_HIP_CHECK(hipEventRecord(ctx.tail_done[parity], tail_stream));
+    ctx.tail_pending[parity] = true;
+    ctx.tail_layout = layout;
+    ctx.tail_parity = parity ^ 1;
+    // the tail before this one has had this batch's front and accumulation to finish beside: the
+    // caller's stream picks it up here (so a deferred call's result is complete on the stream
+    // once the next call has been enqueued)
+    ctx.join_tail(stream, parity ^ 1);
   }
   if (timing) ctx.timer.calls += 1;
   g_kernel_launches += 10;

@@ -1132,6 +1132,9 @@ __global__ void __launch_bounds__(kReduceThreads)
              const task_desc* __restrict__ tasks, u32 lane_log2) {
   using point = typename C::point;
   __shared__ point tree[kReduceThreads];
+  // a latency chain at one wavefront per SIMD: when it runs beside another batch's k_accumulate
+  // (msm_context::tail) its instructions go first, the accumulation fills the slots it leaves
+  __builtin_amdgcn_s_setprio(3);
   const task_desc task = tasks[blockIdx.y];
   const u32 nb = task.num_buckets;
   const u32 seg_log2 = task.segment_log2; // k_accumulate's segments: where the head partials are
@@ -1291,6 +1294,7 @@ __global__ void __launch_bounds__(kCombineThreads)
              u32 w_hi_arg, int first, int last, u32 reduce_seg_log2) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
+  __builtin_amdgcn_s_setprio(3); // one workgroup per column, possibly beside k_accumulate (k_reduce)
   const column_desc col = columns[blockIdx.x];
   const u32 tid = threadIdx.x;
   u8* dst = out + static_cast<u64>(blockIdx.x) * out_stride;

@@ -79,16 +79,19 @@ void bzamd_stage_timing_begin(uint64_t max_calls);
 void bzamd_stage_timing_begin_masked(uint64_t max_calls, uint32_t stage_mask);
 uint64_t bzamd_stage_timing_collect(double* out_ms);
 
-/* Throughput mode for a sequence of device-resident MSM calls.  The last stage of a call -- per
- * column ONE workgroup running the dependent chain of ~250 doublings and the encoding's 250 squarings
- * -- leaves the rest of the machine idle (0.19 of a 1.24 ms call at 2^20 curve25519 rows).
+/* Throughput mode for a sequence of device-resident MSM calls.  The last two stages of a call with
+ * few columns are latency chains that leave the machine nearly idle -- the bucket reduction runs one
+ * wavefront per SIMD, the final stage ONE workgroup per column (~250 dependent doublings and the
+ * encoding's 250 squarings): 0.39 of a 1.24 ms call at 2^20 curve25519 rows.
  * bzamd_pipeline_next() makes the NEXT MSM enqueued through a device entry point of this header
  * (bzamd_msm_device*, bzamd_fixed_packed_multiexponentiation_device) on the current device run
- * that stage on an internal stream, beside the generator conversion, recoding
- * and sorting of the call that follows; the caller's stream does not wait for it.  The commitments
- * of such a call are complete on `stream` only once a later such call on the device
- * has been enqueued on it, or after bzamd_pipeline_flush(stream): do not read them earlier.  One
- * caller thread per device.  (Measured on MI355X, 2^20 rows: 1.07 instead of 1.24 ms per call.) */
+ * those stages on an internal stream, beside the generator conversion, recoding, sorting and
+ * accumulation of the call that follows (which must have the same shape to overlap: the engine
+ * otherwise simply waits); the caller's stream does not wait for them.  The commitments of such a
+ * call are complete on `stream` only once a later such call on the device has been enqueued on
+ * it, or after bzamd_pipeline_flush(stream): do not read them earlier.  Calls with four or more
+ * columns ignore the request (their tails fill the machine).  One caller thread per device.
+ * (Measured on MI355X, 2^20 rows: ~1.0 instead of 1.24 ms per call.) */
 void bzamd_pipeline_next(void);
 void bzamd_pipeline_flush(void* stream);
 
