@@ -940,6 +940,13 @@ template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 d
 #ifndef BZ_ACC_PIPELINE
 #define BZ_ACC_PIPELINE 2
 #endif
+// wave priorities (s_setprio, 0..3) of the two tail kernels, see k_reduce
+#ifndef BZ_REDUCE_PRIO
+#define BZ_REDUCE_PRIO 3
+#endif
+#ifndef BZ_HORNER_PRIO
+#define BZ_HORNER_PRIO 3
+#endif
 template <class C>
 __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_simd)
     k_accumulate(typename C::point* __restrict__ bucket_sums, typename C::point* __restrict__ heads,
@@ -1134,7 +1141,7 @@ __global__ void __launch_bounds__(kReduceThreads)
   __shared__ point tree[kReduceThreads];
   // a latency chain at one wavefront per SIMD: when it runs beside another batch's k_accumulate
   // (msm_context::tail) its instructions go first, the accumulation fills the slots it leaves
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(BZ_REDUCE_PRIO);
   const task_desc task = tasks[blockIdx.y];
   const u32 nb = task.num_buckets;
   const u32 seg_log2 = task.segment_log2; // k_accumulate's segments: where the head partials are
@@ -1294,7 +1301,7 @@ __global__ void __launch_bounds__(kCombineThreads)
              u32 w_hi_arg, int first, int last, u32 reduce_seg_log2) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
-  __builtin_amdgcn_s_setprio(3); // one workgroup per column, possibly beside k_accumulate (k_reduce)
+  __builtin_amdgcn_s_setprio(BZ_HORNER_PRIO); // one workgroup per column, possibly beside k_accumulate
   const column_desc col = columns[blockIdx.x];
   const u32 tid = threadIdx.x;
   u8* dst = out + static_cast<u64>(blockIdx.x) * out_stride;
