@@ -290,6 +290,10 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
     signal(ds.copy_stream, ds.stream);
     const std::vector<host_column> chunk(cols.begin() + begin, cols.begin() + end);
     u8* out_k = d_out + begin * static_cast<size_t>(out_stride);
+    // throughput mode between the chunks of a call (msm_context::tail): the bucket reduction and
+    // the Horner chain of a chunk of a few long columns run beside the next chunk (a call of one
+    // chunk has nothing to overlap with and keeps the plain path)
+    if (begin != 0 || end < cols.size()) msm_context_defer_next_tail(ds.ctx);
     if (resident) {
       vt.msm_resident(*ds.ctx, out_k, out_stride, projective_out, chunk, d_addends, ds.stream,
                       tables.windows != 0 ? &tables : nullptr);
@@ -298,6 +302,7 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
     }
     begin = end;
   }
+  msm_context_join_tail(ds.ctx, ds.stream);
   return d_out;
 }
 

@@ -100,13 +100,13 @@ struct msm_context {
   // depend on it; joined before k_accumulate
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  // Device copy of the descriptors (columns | tasks | packed-recode ranges) of the last batch
-  // enqueued on this context, in a block of its own, and `desc_shadow` = the bytes it holds.  A
-  // batch whose descriptors are byte-identical -- the same shapes over the same device pointers: a
-  // caller committing again and again from the same buffers -- skips the pinned staging, the H2D
-  // copy and the two stream bubbles around it (~15 us of a 1.3 ms call).  Only msm_enqueue_batch
-  // writes the block, always on the stream of the call, and calls on one context are ordered
-  // (order_after_previous), so the block never changes under a kernel that reads it.
+  // Device copies of the descriptors (columns | tasks | packed-recode ranges) in blocks of their
+  // own -- two, one per tail set (below; plain calls use block 0) -- and `desc_shadow` = the bytes
+  // each holds.  A batch whose descriptors are byte-identical to its block's -- the same shapes
+  // over the same device pointers: a caller committing again and again from the same buffers --
+  // skips the pinned staging, the H2D copy and the two stream bubbles around it (~15 us of a 1.3 ms
+  // call).  Only msm_enqueue_batch writes a block, on the stream of the call and after the tail
+  // that read it last has been joined; calls on one context are ordered (order_after_previous).
   // Tail stream.  The two stages after k_accumulate are latency chains that leave the machine
   // nearly idle: k_reduce runs one wavefront per SIMD, k_horner ONE workgroup per column (~250
   // dependent doublings and the encoding's 250 squarings); together 0.39 of a 1.24 ms call at
@@ -152,17 +152,18 @@ struct msm_context {
     join_tail(stream, 0);
     join_tail(stream, 1);
   }
-  char* desc_dev = nullptr;
-  size_t desc_cap = 0;
-  std::vector<char> desc_shadow, desc_image;
-  char* descriptor_block(size_t bytes) {
-    if (bytes > desc_cap) {
-      if (desc_dev != nullptr) BZ_HIP_CHECK(hipFree(desc_dev)); // waits for the kernels reading it
-      desc_cap = bytes + bytes / 2 + 4096;
-      BZ_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&desc_dev), desc_cap));
-      desc_shadow.clear();
+  char* desc_dev[2] = {nullptr, nullptr};
+  size_t desc_cap[2] = {0, 0};
+  std::vector<char> desc_shadow[2], desc_image;
+  char* descriptor_block(u32 which, size_t bytes) {
+    if (bytes > desc_cap[which]) {
+      // hipFree waits for the kernels reading the block
+      if (desc_dev[which] != nullptr) BZ_HIP_CHECK(hipFree(desc_dev[which]));
+      desc_cap[which] = bytes + bytes / 2 + 4096;
+      BZ_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&desc_dev[which]), desc_cap[which]));
+      desc_shadow[which].clear();
     }
-    return desc_dev;
+    return desc_dev[which];
   }
   bool overlap_prepare = false; // BLITZAR_AMD_OVERLAP_PREPARE=1 (no gain for the HBM-bound per-point conversion)
   ~msm_context() {
@@ -170,7 +171,9 @@ struct msm_context {
     if (fork != nullptr) (void)hipEventDestroy(fork);
     if (join != nullptr) (void)hipEventDestroy(join);
     if (side != nullptr) (void)hipStreamDestroy(side);
-    if (desc_dev != nullptr) (void)hipFree(desc_dev);
+    for (auto& d : desc_dev) {
+      if (d != nullptr) (void)hipFree(d);
+    }
     if (tail_fork != nullptr) (void)hipEventDestroy(tail_fork);
     for (auto& e : tail_done) {
       if (e != nullptr) (void)hipEventDestroy(e);
@@ -406,22 +409,28 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     std::memcpy(image.data() + col_bytes + task_bytes, ranges.data(),
                 sizeof(recode_range) * ranges.size());
   }
-  // pending tails share descriptors and arena layout with this batch, or they go first
-  const u64 layout = (static_cast<u64>(msm_workspace_bytes<C>(plan, d_addends == nullptr,
-                                                               b.partial_stride, tail_on_side))
-                      << 8) ^
-                     (static_cast<u64>(C::curve_id) << 4) ^ (d_addends == nullptr ? 2u : 0u) ^
-                     (tail_on_side ? 1u : 0u);
-  if (ctx.any_tail_pending() && (layout != ctx.tail_layout || image != ctx.desc_shadow)) {
-    ctx.join_tail(stream);
+  // pending tails were carved from the arena exactly like this batch (every size that enters the
+  // carving below, the curve and the mode), or they go first
+  u64 layout = 0xcbf29ce484222325ull;
+  for (u64 v : {static_cast<u64>(plan.total_entries), static_cast<u64>(plan.total_groups),
+                static_cast<u64>(plan.total_buckets), static_cast<u64>(plan.total_segments),
+                static_cast<u64>(plan.max_rows), static_cast<u64>(num_tasks),
+                static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
+                static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
+                static_cast<u64>(d_addends == nullptr), static_cast<u64>(tail_on_side)}) {
+    layout = (layout ^ v) * 0x100000001b3ull;
   }
-  char* desc = ctx.descriptor_block(desc_bytes);
-  if (image != ctx.desc_shadow) {
+  if (ctx.any_tail_pending() && layout != ctx.tail_layout) ctx.join_tail(stream);
+  // this batch's tail set and descriptor block (plain calls: set 0)
+  const u32 parity = tail_on_side ? ctx.tail_parity : 0;
+  char* desc = ctx.descriptor_block(parity, desc_bytes);
+  if (image != ctx.desc_shadow[parity]) {
+    ctx.join_tail(stream, parity); // the tail that read this block two batches ago
     char* staged = static_cast<char*>(ctx.descriptors.acquire(desc_bytes));
     std::memcpy(staged, image.data(), desc_bytes);
     BZ_HIP_CHECK(hipMemcpyAsync(desc, staged, desc_bytes, hipMemcpyHostToDevice, stream));
     ctx.descriptors.release(stream);
-    ctx.desc_shadow = image;
+    ctx.desc_shadow[parity] = image;
   }
   b.cols = reinterpret_cast<column_desc*>(desc);
   b.tasks = reinterpret_cast<task_desc*>(desc + col_bytes);
@@ -466,7 +475,6 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   b.bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
   b.segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
   // what the tail stages read: two sets in throughput mode, this batch uses set `parity`
-  const u32 parity = tail_on_side ? ctx.tail_parity : 0;
   for (u32 set = 0; set < (tail_on_side ? 2u : 1u); ++set) {
     u32* bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
     point* bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);

@@ -412,15 +412,18 @@ def test_pipelined_calls(gpu_backend, oracle):
         gens = util.generators_for(curve_id, n)
         g_host = np.ascontiguousarray(util.api_generators(curve_id, gens))
         d_gens = torch.from_numpy(g_host.copy()).to(dev)
-        for rows, nbytes in ((n, 32), (n - 11, 32), (n, 5)):
+        for rows, nbytes in ((n, 32), (n - 11, 32), (n, 5), (n, 32)):
             col = rng.integers(0, 256, (rows, nbytes), dtype=np.uint8)
             want = oracle.commit(curve_id, [(col, False)], gens)
             d_col = torch.from_numpy(col.copy()).to(dev)
             desc = (api.sxt_sequence_descriptor * 1)()
             desc[0] = api.sxt_sequence_descriptor(nbytes, rows, d_col.data_ptr(), 0)
             jobs.append((curve_id, d_gens, d_col, desc, want))
-    # every job three times in a row (identical descriptors), jobs interleaved (changing ones)
-    order = [j for j in range(len(jobs)) for _ in range(3)] + list(range(len(jobs))) * 2
+    # every job three times in a row (identical descriptors), jobs interleaved (changing ones),
+    # and two jobs of one shape over different buffers alternating (the overlapping path with a
+    # descriptor upload per call)
+    order = ([j for j in range(len(jobs)) for _ in range(3)] + list(range(len(jobs))) * 2 +
+             [0, 3] * 4 + [4, 7] * 3)
     outs, copies = [], []
     for j in order:
         curve_id, d_gens, _, desc, want = jobs[j]
