@@ -453,6 +453,48 @@ def test_pipelined_calls(gpu_backend, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(got_a.cpu().numpy(), want) and np.array_equal(got_b.cpu().numpy(), want)
     lib.bzamd_generators_free(h)
+    # a random mix: deferred and plain calls, a five-column call (which ignores the request),
+    # flushes now and then; a result is read once something was enqueued after its call
+    curve_id, d_gens = jobs[0][0], jobs[0][1]
+    five = (api.sxt_sequence_descriptor * 5)()
+    for c in range(5):
+        five[c] = jobs[c % 4][3][0]
+    want5 = np.concatenate([jobs[c % 4][4] for c in range(5)])
+    pending = []
+    for _ in range(40):
+        kind = int(rng.integers(0, 4))
+        if kind == 3:
+            out = torch.zeros((5, 32), dtype=torch.uint8, device=dev)
+            if rng.integers(0, 2):
+                lib.bzamd_pipeline_next()
+            lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 5, five,
+                                 ctypes.c_void_p(d_gens.data_ptr()), stream)
+            want_k, deferred = want5, False
+        else:
+            j = int(rng.integers(0, 4))
+            out = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+            deferred = kind != 0
+            if deferred:
+                lib.bzamd_pipeline_next()
+            lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, jobs[j][3],
+                                 ctypes.c_void_p(d_gens.data_ptr()), stream)
+            want_k = jobs[j][4]
+        for w, o in pending:  # complete on the stream by now
+            copies.append((w, o.clone()))
+        pending = [(want_k, out)] if deferred else []
+        if not deferred:
+            copies.append((want_k, out.clone()))
+        if rng.integers(0, 5) == 0:
+            lib.bzamd_pipeline_flush(stream)
+            for w, o in pending:
+                copies.append((w, o.clone()))
+            pending = []
+    lib.bzamd_pipeline_flush(stream)
+    for w, o in pending:
+        copies.append((w, o.clone()))
+    torch.cuda.synchronize()
+    for w, got in copies[len(order):]:
+        assert np.array_equal(got.cpu().numpy(), w)
 
 
 @pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
