@@ -426,7 +426,6 @@ def main():
     generators = torch.empty((n, gen_bytes), dtype=torch.uint8, device=dev)
     lib.bzamd_ristretto255_generators_device(vp(generators), 0, n, stream)
     out = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
-    gathered = torch.zeros((world, 32), dtype=torch.uint8, device=dev)
     desc = (api.sxt_sequence_descriptor * 1)()
     desc[0] = api.sxt_sequence_descriptor(nbytes, n, scalars.data_ptr(), 0)
     torch.cuda.synchronize()
@@ -434,26 +433,26 @@ def main():
     # The steps run in the library's throughput mode (bzamd_pipeline_next, include/blitzar_amd.h):
     # the last stage of step k -- one workgroup walking the column's chain of doublings -- runs on
     # the engine's tail stream beside the generator conversion, recoding and sorting of step k + 1.
-    # A step's commitment is complete on the stream once the next step has been enqueued, so the
-    # all-gather of step k carries the commitment of step k - 1 (two output buffers), and a flush
-    # plus the last gather close the sequence inside the timed region: K MSMs, K gathers.
-    outs = [out, torch.zeros_like(out)]
+    # Every step writes its commitment to its own row of `outs`; a flush and -- with more than one
+    # rank -- ONE all-gather of the ranks' K x 32 bytes close the sequence inside the timed region
+    # (fewer, larger collectives: the commitments of a job are needed when the job is done).
+    max_steps = max(args.steps, args.warmup, 1)
+    outs = torch.zeros((max_steps, 32), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world * max_steps, 32), dtype=torch.uint8, device=dev)
 
     def step(k):
         lib.bzamd_pipeline_next()
-        lib.bzamd_msm_device(curve_id, vp(outs[k & 1]), 1, desc, vp(generators), stream)
-        if world > 1 and k > 0:
-            coll.all_gather(gathered, outs[(k - 1) & 1])
+        lib.bzamd_msm_device(curve_id, vp(outs[k:k + 1]), 1, desc, vp(generators), stream)
 
-    def finish(k_last):
+    def finish():
         lib.bzamd_pipeline_flush(stream)
         if world > 1:
-            coll.all_gather(gathered, outs[k_last & 1])
+            coll.all_gather(gathered, outs)
 
     for k in range(args.warmup):
         step(k)
     if args.warmup:
-        finish(args.warmup - 1)
+        finish()
     torch.cuda.synchronize()
     if world > 1:
         coll.barrier()
@@ -465,16 +464,19 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
-    finish(args.steps - 1)
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         coll.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed_stages, calls = clock.collect(args.steps)
-    timed_output = outs[(args.steps - 1) & 1].cpu().numpy().copy()
+    all_outputs = outs[:args.steps].cpu().numpy()
+    timed_output = all_outputs[-1:].copy()
+    assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
     if world > 1:
-        assert np.array_equal(gathered.cpu().numpy()[rank], timed_output[0])
+        mine = gathered.cpu().numpy().reshape(world, max_steps, 32)[rank, :args.steps]
+        assert np.array_equal(mine, all_outputs), "all-gather returned something else"
     # untimed passes: the six stage times, and the latency of a lone call (no throughput mode)
     stage_steps = min(args.steps, 50)
     clock = StageClock(lib, stage_steps)
