@@ -81,10 +81,10 @@ struct stage_timer {
 // shared by every MSM call enqueued on that device.  Calls are asynchronous on a caller stream, so
 // two things keep them from trampling each other's workspace:
 //   * `mu` serialises the host side (arena cursor, staging ring, timer) across caller threads;
-//   * every call records `last_done` on its stream when it has enqueued its last kernel, and a
-//     call arriving on a DIFFERENT stream first makes that stream wait for the event -- calls on
-//     one device therefore execute one after the other whatever streams they come in on (they
-//     could not overlap usefully anyway: k_accumulate fills the machine).
+//   * a call arriving on a DIFFERENT stream than the previous one first makes its stream wait for
+//     everything enqueued on the previous stream (`order_after_previous`) -- calls on one device
+//     therefore execute one after the other whatever streams they come in on; what does overlap
+//     is the tail of a call with the call after it, on the context's own tail stream (below).
 struct msm_context {
   device_arena arena;
   host_stage_ring descriptors; // pinned copies of the column / task descriptors in flight
@@ -116,10 +116,10 @@ struct msm_context {
   // and the next front writes -- bucket ends, bucket sums, head partials, partials, task totals --
   // then exists twice, and consecutive calls alternate (`tail_parity`); a call waits for the tail
   // that used its set two calls ago (`tail_done[parity]`) before its sort rewrites the bucket ends.
-  // That only works while consecutive calls carve the arena identically (same descriptors, same
-  // curve, same mode: `tail_layout`); any other call first joins every pending tail (`join_tail`),
-  // and so does a changed descriptor block, a re-allocation of the arena, the end of a call that is
-  // not deferred, and bzamd_pipeline_flush.  Used across calls issued through bzamd_pipeline_next
+  // That only works while consecutive calls carve the arena identically (same shapes, same curve,
+  // same mode: `tail_layout`); any other call first joins every pending tail (`join_tail`), and so
+  // does a re-allocation of the arena, the end of a call that is not deferred, and
+  // bzamd_pipeline_flush; a descriptor block is rewritten after the tail that read it was joined.  Used across calls issued through bzamd_pipeline_next
   // (whose results are complete on the caller's stream only after a later call or a flush); any
   // other call keeps everything on the caller's stream -- plain stream semantics, and forking
   // would only add stream bubbles (measured: 1.237 -> 1.266 ms at config 2).  The tail kernels
@@ -188,15 +188,23 @@ struct msm_context {
     }
     return side;
   }
-  // order `stream` behind the previous call on this context (no-op on the same stream)
+  // order `stream` behind the previous call on this context (no-op on the same stream).  The event
+  // is recorded only now, on the previous call's stream -- behind that call and whatever the caller
+  // enqueued there since: a superset -- so that a sequence of calls on ONE stream pays no event
+  // record per call.
   void order_after_previous(hipStream_t stream) {
-    if (has_last && last_stream != stream) BZ_HIP_CHECK(hipStreamWaitEvent(stream, last_done, 0));
-  }
-  void mark_enqueued(hipStream_t stream) {
+    if (!has_last || last_stream == stream) return;
     if (last_done == nullptr) {
       BZ_HIP_CHECK(hipEventCreateWithFlags(&last_done, hipEventDisableTiming));
     }
-    BZ_HIP_CHECK(hipEventRecord(last_done, stream));
+    if (hipEventRecord(last_done, last_stream) != hipSuccess) {
+      (void)hipGetLastError(); // the caller destroyed that stream: its work drains on its own
+      BZ_HIP_CHECK(hipDeviceSynchronize());
+      return;
+    }
+    BZ_HIP_CHECK(hipStreamWaitEvent(stream, last_done, 0));
+  }
+  void mark_enqueued(hipStream_t stream) {
     last_stream = stream;
     has_last = true;
   }

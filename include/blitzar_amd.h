@@ -11,9 +11,11 @@
  *
  * Concurrency: the engine keeps one workspace per device.  Calls on one device are executed in the
  * order they were enqueued, whatever streams they arrive on (a call on another stream first waits
- * for the previous call's last kernel; they could not overlap usefully anyway, k_accumulate fills
- * the machine), and the host side of every call takes the device context's lock, so several host
- * threads may enqueue.  The blocking sxt_* entry points serialise on one process-wide lock.
+ * for everything enqueued so far on the stream of the previous call; do not destroy a stream the
+ * engine may still have to wait for), and the host side of every call takes the device context's
+ * lock, so several host threads may enqueue.  What can overlap is the tail of one call with the
+ * next call (bzamd_pipeline_next below).  The blocking sxt_* entry points serialise on one
+ * process-wide lock.
  */
 #ifndef BLITZAR_AMD_BLITZAR_AMD_H
 #define BLITZAR_AMD_BLITZAR_AMD_H
