@@ -53,6 +53,7 @@ msm_context* msm_context_new() {
   if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_PREPARE")) ctx->overlap_prepare = v[0] != '0';
   if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_TAILS")) ctx->overlap_tails = v[0] != '0';
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_REDUCE")) ctx->tail_includes_reduce = v[0] != '0';
+  if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) ctx->two_tail_streams = v[0] != '1';
 
   return ctx;
 }

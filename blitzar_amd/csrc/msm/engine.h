@@ -125,8 +125,12 @@ struct msm_context {
   // would only add stream bubbles (measured: 1.237 -> 1.266 ms at config 2).  The tail kernels
   // raise their wave priority (s_setprio): beside a k_accumulate that owns every SIMD they would
   // otherwise crawl (config 3: k_horner 1.3 -> 6.7 ms) and become the pipeline's bottleneck.
-  hipStream_t tail = nullptr;
-  hipEvent_t tail_fork = nullptr;
+  // (Two tail streams: k_horner of call i on the second one, so that it also runs beside k_reduce of
+  // call i + 1 -- the tails of a sequence then cost max(reduce, horner) per call instead of their
+  // sum, which matters on the pool's slower kind of box, where they add up to more than the front
+  // and the accumulation of a call; on the faster kind 1.037 -> 1.025 ms per call.)
+  hipStream_t tail = nullptr, tail2 = nullptr;
+  hipEvent_t tail_fork = nullptr, tail_mid = nullptr;
   hipEvent_t tail_done[2] = {nullptr, nullptr};
   bool tail_pending[2] = {false, false};
   u32 tail_parity = 0;
@@ -134,10 +138,13 @@ struct msm_context {
   bool defer_tail = false;    // the next call leaves its tail pending (msm_context_defer_next_tail)
   bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: never fork
   bool tail_includes_reduce = true; // BLITZAR_AMD_TAIL_REDUCE=0: only k_horner forks
+  bool two_tail_streams = true;     // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
   hipStream_t tail_stream() {
     if (tail == nullptr) {
       BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail2, hipStreamNonBlocking));
       BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_fork, hipEventDisableTiming));
+      BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_mid, hipEventDisableTiming));
       for (auto& e : tail_done) BZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     return tail;
@@ -175,6 +182,8 @@ struct msm_context {
       if (d != nullptr) (void)hipFree(d);
     }
     if (tail_fork != nullptr) (void)hipEventDestroy(tail_fork);
+    if (tail_mid != nullptr) (void)hipEventDestroy(tail_mid);
+    if (tail2 != nullptr) (void)hipStreamDestroy(tail2);
     for (auto& e : tail_done) {
       if (e != nullptr) (void)hipEventDestroy(e);
     }
@@ -580,6 +589,12 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
   });
   if (!ctx.tail_includes_reduce) fork();
+  if (tail_on_side && ctx.tail_includes_reduce && ctx.two_tail_streams) {
+    // k_horner on the second tail stream: beside the next call's k_reduce on the first
+    BZ_HIP_CHECK(hipEventRecord(ctx.tail_mid, tail_stream));
+    tail_stream = ctx.tail2;
+    BZ_HIP_CHECK(hipStreamWaitEvent(tail_stream, ctx.tail_mid, 0));
+  }
   ctx.timer.timed(timing, 5, tail_stream, [&] {
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, tail_stream, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
