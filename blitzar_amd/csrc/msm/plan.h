@@ -70,6 +70,10 @@ constexpr u32 kReduceSegmentLog2Max = BZ_REDUCE_SEGMENT_LOG2_MAX;
 constexpr u64 kReduceFillLanes = 131072;
 inline u32 choose_reduce_segment_log2(u64 total_buckets, u32 max_task_buckets) {
   u32 s = kReduceSegmentLog2;
+  // narrow columns (bytes, booleans: 128..1024 buckets per task) have one block per task anyway:
+  // fewer buckets per lane, down to one, shorten its chain (a 1-byte column of 2^20 rows: k_reduce
+  // 0.25 -> 0.1 ms of a 0.6 ms call)
+  while (s > 0 && (static_cast<u64>(kReduceThreads) << s) > max_task_buckets) --s;
   // ... as long as the largest task still fills a block's 256 lanes (idle waves of a block hold
   // registers the other blocks of the CU could use)
   while (s < kReduceSegmentLog2Max && (total_buckets >> (s + 1)) >= kReduceFillLanes &&
