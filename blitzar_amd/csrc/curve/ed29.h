@@ -92,6 +92,25 @@ BZ_HD ed29_cached_packed pack(const ed29_cached& c) {
   return m;
 }
 
+// row `row` of a table of packed addends with its first two 32-byte pieces (Y+X | Y-X) exchanged
+// when `negate`: by address, as 16-byte loads (k_accumulate's gather)
+struct alignas(16) u32x4 {
+  u32 v[4];
+};
+BZ_HD ed29_cached_packed gather_signed(const ed29_cached_packed* table, u32 row, bool negate) {
+  const u32x4* src = reinterpret_cast<const u32x4*>(table + row);
+  const u32 a = negate ? 2u : 0u;
+  ed29_cached_packed q;
+  u32x4* dst = reinterpret_cast<u32x4*>(&q);
+  dst[0] = src[a];
+  dst[1] = src[a + 1];
+  dst[2] = src[2 - a];
+  dst[3] = src[3 - a];
+#pragma unroll
+  for (int i = 4; i < 8; ++i) dst[i] = src[i];
+  return q;
+}
+
 BZ_HD ed29_cached unpack(const ed29_cached_packed& m) {
   return {unpack_words(m.w), unpack_words(m.w + 8), unpack_words(m.w + 16), unpack_words(m.w + 24)};
 }
@@ -107,6 +126,29 @@ BZ_HD ed29_point add_cached(const ed29_point& p, const ed29_cached& q, bool nega
   const fe29 ymx = f29::sub(p.Y, p.X);               // B 3
   const fe29 a = f29::mul(ypx, qa);                  // 2 * 1
   const fe29 b = f29::mul(ymx, qb);                  // 3 * 1
+  const fe29 c = f29::mul(p.T, qt);                  // 1 * 2
+  const fe29 zz = f29::mul(p.Z, q.Z);                // 1 * 1
+  const fe29 d = f29::add(zz, zz);                   // B 2
+  const fe29 ez = f29::add(d, c);                    // B 3
+  const fe29 et = f29::weak_reduce(f29::sub(d, c));  // B 4 -> 1
+  const fe29 ex = f29::sub(a, b);                    // B 3
+  const fe29 ey = f29::add(a, b);                    // B 2
+  ed29_point r;
+  r.X = f29::mul(ex, et); // 3 * 1
+  r.Y = f29::mul(ey, ez); // 2 * 3
+  r.Z = f29::mul(ez, et); // 3 * 1
+  r.T = f29::mul(ex, ey); // 3 * 2
+  return r;
+}
+
+// the same with q.YpX / q.YmX already exchanged when `negate` (k_accumulate gathers the two 32-byte
+// pieces of the packed row in the order the digit's sign asks for): only 2dT still depends on it
+BZ_HD ed29_point add_cached_presigned(const ed29_point& p, const ed29_cached& q, bool negate) {
+  const fe29 qt = f29::cneg_xad(q.T2d, negate);      // B 2
+  const fe29 ypx = f29::add(p.Y, p.X);               // B 2
+  const fe29 ymx = f29::sub(p.Y, p.X);               // B 3
+  const fe29 a = f29::mul(ypx, q.YpX);               // 2 * 1
+  const fe29 b = f29::mul(ymx, q.YmX);               // 3 * 1
   const fe29 c = f29::mul(p.T, qt);                  // 1 * 2
   const fe29 zz = f29::mul(p.Z, q.Z);                // 1 * 1
   const fe29 d = f29::add(zz, zz);                   // B 2

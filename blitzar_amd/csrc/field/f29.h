@@ -86,6 +86,19 @@ BZ_HD fe29 sub(const fe29& f, const fe29& g) {
 
 BZ_HD fe29 neg(const fe29& f) { return sub(zero(), f); }
 
+// b ? neg(f) : f without a select: K - t = (t ^ ~0) + (K + 1) in 32-bit arithmetic, so both cases
+// are (t ^ m) + c with m = b ? ~0 : 0 and c = b ? K + 1 : 0 -- one v_xad_u32 per limb
+BZ_HD fe29 cneg_xad(const fe29& f, bool b) {
+  const u32 m = b ? ~0u : 0u;
+  const u32 c0 = b ? ((1u << 30) - 2 * kWrap) + 1 : 0u;
+  const u32 c = b ? ((1u << 30) - 2) + 1 : 0u;
+  fe29 h;
+  h.v[0] = (f.v[0] ^ m) + c0;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) h.v[i] = (f.v[i] ^ m) + c;
+  return h;
+}
+
 // limbs back below 2^29 + eps (one carry sweep with the wrap folded into limb 0, two steps)
 BZ_HD fe29 weak_reduce(const fe29& f) {
   fe29 h;

@@ -71,6 +71,19 @@ struct ed25519_msm {
   BZ_HD static void accumulate(point& acc, const operand& q, bool negate) {
     acc = ed29::add_cached(acc, q, negate);
   }
+  // k_accumulate's gather: the row's first two 32-byte pieces (Y+X | Y-X) arrive exchanged when
+  // the digit is negative -- by address, two 16-byte loads each -- so the addition needs no selects
+  // on them (18 v_cndmask per addition) and only conditions 2dT (`accumulate_gathered`)
+#ifndef BZ_SIGNED_GATHER
+#define BZ_SIGNED_GATHER 1
+#endif
+  static constexpr bool has_signed_gather = BZ_SIGNED_GATHER != 0;
+  BZ_HD static addend gather(const addend* table, u32 row, bool negate) {
+    return ed29::gather_signed(table, row, negate);
+  }
+  BZ_HD static void accumulate_gathered(point& acc, const operand& q, bool negate) {
+    acc = ed29::add_cached_presigned(acc, q, negate);
+  }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     return ed29::pack(ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]));
   }
@@ -187,6 +200,7 @@ struct ed25519_niels_msm : ed25519_msm {
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     acc = ed29::add_niels(acc, q, negate);
   }
+  static constexpr bool has_signed_gather = false; // 36-byte limb pieces: no aligned exchange
   using operand = ed29_niels; // stored as limbs: nothing to unpack
   BZ_HD static operand stage(const addend& q) {
     operand o = q;
@@ -255,6 +269,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
 #endif
   static constexpr bool accumulate_pinned = BZ_SW_ACCUMULATE_PINNED != 0 && G29::N <= 9;
   static constexpr bool has_batched_prepare = false;
+  static constexpr bool has_signed_gather = false;
   static constexpr bool has_wave_encode = false;
   static constexpr bool has_wave_add_multiple = false;
   // k_horner's dependent chain on one wavefront: doublings split over the lanes of each DPP quad

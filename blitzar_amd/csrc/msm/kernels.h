@@ -990,7 +990,15 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   typename C::point* flush_to = owned ? sums + b : heads + task.segment_base + seg;
   u32 e_cur = idx[lo];
   u32 e_next = lo + 1 < hi ? idx[lo + 1] : 0;
-  typename C::addend staged = addends[e_cur & 0x7fffffffu];
+  // (curves with C::has_signed_gather fetch the row in the order the digit's sign asks for)
+  auto gather = [&](u32 entry) {
+    if constexpr (C::has_signed_gather) {
+      return C::gather(addends, entry & 0x7fffffffu, (entry >> 31) != 0);
+    } else {
+      return addends[entry & 0x7fffffffu];
+    }
+  };
+  typename C::addend staged = gather(e_cur);
   for (u32 i = lo; i < hi; ++i) {
     if (i == b_end) {
       *flush_to = acc;
@@ -1010,11 +1018,15 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
     // the gather is unconditional (the last iteration re-reads its own row, a cache hit): a load
     // under `if (i + 1 < hi)` writes its registers in some lanes only, and hipcc then keeps two
     // copies of the row and moves it back and forth (bn254: 16 v_mov_b64 per iteration)
-    const u32 row = (i + 1 < hi ? e_next : e_cur) & 0x7fffffffu;
+    const u32 next_entry = i + 1 < hi ? e_next : e_cur;
     e_cur = e_next;
-    staged = addends[row];
+    staged = gather(next_entry);
     if (i + 2 < hi) e_next = idx[i + 2];
-    C::accumulate(acc, q, negate);
+    if constexpr (C::has_signed_gather) {
+      C::accumulate_gathered(acc, q, negate);
+    } else {
+      C::accumulate(acc, q, negate);
+    }
   }
 #else
   // software pipeline, one entry ahead: the gather of the next addend (two dependent loads:

@@ -216,6 +216,12 @@ def ed29_add(a, b, negate=False):
     return out
 
 
+def ed29_add_gathered(a, b, negate=False):
+    out = np.zeros(20, np.uint64)
+    lib().bz_ed29_add_gathered(_p(out), _p(_c(a)), _p(_c(b)), ctypes.c_int(1 if negate else 0))
+    return out
+
+
 def ed29_dbl_n(a, k):
     out = np.zeros(20, np.uint64)
     lib().bz_ed29_dbl_n(_p(out), _p(_c(a)), ctypes.c_int(k))

@@ -315,6 +315,19 @@ void bz_ed29_add(u64* out, const u64* a, const u64* b, int negate) {
   ed_point e = ed29::to_ed(r);
   std::memcpy(out, &e, 160);
 }
+// the same through what k_accumulate does with a packed row: gathered with its first two pieces
+// exchanged by address when negating, unpacked, 2dT negated by xor-add
+void bz_ed29_add_gathered(u64* out, const u64* a, const u64* b, int negate) {
+  ed_point p, q;
+  std::memcpy(&p, a, 160);
+  std::memcpy(&q, b, 160);
+  const ed29_cached_packed row[1] = {ed29::pack(ed29::cached_from_ed(q))};
+  const ed29_cached_packed g = ed29::gather_signed(row, 0, negate != 0);
+  const ed29_point acc =
+      ed29::add_cached_presigned(ed29::from_ed(p), ed29::unpack(g), negate != 0);
+  ed_point e = ed29::to_ed(acc);
+  std::memcpy(out, &e, 160);
+}
 void bz_ed29_dbl_n(u64* out, const u64* a, int k) {
   ed_point p;
   std::memcpy(&p, a, 160);

@@ -306,6 +306,10 @@ def test_ed29_group_law_matches_reference(oracle):
         assert np.array_equal(canon(hooks.ed29_add(a, b, True)), canon(hooks.ed_sub(a, b)))
         assert np.array_equal(canon(hooks.ed29_add(a, a)), canon(oracle.double_projective(0, a)))
         assert np.array_equal(canon(hooks.ed29_add(a, a, True)), np.zeros(32, np.uint8))
+        # k_accumulate's form: packed row gathered in sign order, 2dT negated by xor-add
+        for neg in (False, True):
+            assert np.array_equal(canon(hooks.ed29_add_gathered(a, b, neg)),
+                                  canon(hooks.ed29_add(a, b, neg)))
         d = a
         for k in range(1, 18):
             d = oracle.double_projective(0, d)
