@@ -915,18 +915,20 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
 //--------------------------------------------------------------------------------------------------
 // k_accumulate
 //--------------------------------------------------------------------------------------------------
-// One lane per segment of kSegmentEntries consecutive sorted entries.  The lane walks its entries,
+// One lane per segment of 2^task.segment_log2 (32..128, one value per launch: plan.h) consecutive
+// sorted entries.  The lane walks its entries,
 // gathers each addend from the resident generator array and adds it into a register-resident
 // accumulator; at a bucket boundary the accumulator is flushed.  The lane in whose segment a
 // bucket *starts* owns bucket_sums[bucket]; a lane that begins in the middle of a bucket writes
 // that first partial to heads[segment] instead (k_reduce adds the heads of a bucket to its sum).
-// Every lane therefore does at most kSegmentEntries additions, whatever the digit distribution.
+// Every lane therefore does at most one segment's worth of additions, whatever the digit
+// distribution.
 //
 // Skewed data (many equal scalars) makes one bucket span many whole segments.  Consecutive lanes
 // of a wavefront whose segments lie entirely inside the same bucket fold their partials with a
 // segmented shuffle reduction (taken only when such a run exists: wave-uniform branch), and only
 // the first lane of the run writes a head: `load_bucket` below applies the same geometric rule,
-// so a bucket of m entries costs its consumer m / (32 * 64) additions instead of m / 32.
+// so a bucket of m entries costs its consumer m / (64 segments) additions instead of m / segment.
 template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 delta) {
   static_assert(sizeof(P) % 4 == 0);
   P r;

@@ -9,7 +9,7 @@
 // The digits of a task are sorted by bucket in two passes (kernels.h): the buckets are cut into
 // *groups* of 2^s consecutive buckets, the rows into *slices* (one workgroup each); pass 1
 // partitions every slice's digits by group, pass 2 sorts one group per workgroup inside LDS.  The
-// sorted entry list is then cut into *segments* (kSegmentEntries entries, one lane each) for the
+// sorted entry list is then cut into *segments* (32..128 entries, one lane each) for the
 // bucket accumulation, so the parallelism of every stage is proportional to the number of rows
 // and independent of how the digits are distributed over the buckets.
 //
