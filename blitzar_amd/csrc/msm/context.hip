@@ -43,6 +43,9 @@ msm_context* msm_context_new() {
     msm_context_set_segments(ctx, ctx->tuning.force_segment_log2,
                              static_cast<u32>(std::strtoul(v, nullptr, 10)));
   }
+  if (const char* v = std::getenv("BLITZAR_AMD_DEFER_COLUMNS")) {
+    ctx->tuning.defer_max_columns = static_cast<size_t>(std::strtoul(v, nullptr, 10));
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_SEGMENT_LOG2")) {
     msm_context_set_segments(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)),
                              ctx->tuning.force_reduce_segment_log2);

@@ -285,13 +285,13 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   std::lock_guard<std::mutex> lock(ctx.mu);
   configure_sort_kernels(ctx);
   ctx.order_after_previous(stream);
-  // throughput mode is for latency-bound tails: with many columns k_reduce and k_horner fill the
-  // machine themselves (measured, config 4: 352.5 against 348.0 ms with the fork and the second
-  // set of tail buffers), so such a call ignores the request and completes on the caller's stream
+  // throughput mode is for latency-bound tails: with hundreds of columns k_reduce and k_horner
+  // fill the machine themselves (plan.h, defer_max_columns), so such a call ignores the request
+  // and completes on the caller's stream
   size_t nonempty_columns = 0;
   for (const auto& c : cols) nonempty_columns += c.n != 0 ? 1 : 0;
   const bool defer_tail = ctx.defer_tail && ctx.overlap_tails &&
-                          nonempty_columns < ctx.tuning.throughput_columns;
+                          nonempty_columns < ctx.tuning.defer_max_columns;
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   bool any_signed = false;

@@ -164,6 +164,12 @@ struct msm_tuning {
   double throughput_bucket_cost = BZ_THROUGHPUT_BUCKET_COST;
   u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
   u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
+  // throughput mode (engine.h, msm_context::tail): calls with this many columns or more ignore
+  // bzamd_pipeline_next (BLITZAR_AMD_DEFER_COLUMNS).  Measured on MI355X, curve25519, k columns x 2^20
+  // rows, ms per call lone / in sequence (tools/multi_column_bench.py): 2: 2.41 / 2.03, 4: 4.19 / 3.73,
+  // 8: 7.60 / 7.13, 16: 14.46 / 13.93, 32: 27.73 / 27.22; with 256 columns (bn254) the fork and the
+  // second set of tail buffers cost more than the overlap buys (352.5 against 348.0).
+  size_t defer_max_columns = 64;
   // window tables: gathers from a table beyond the 256 MiB Infinity Cache cost this much more per
   // addition (measured on MI355X: 51 against 43 ps with a 2 GiB curve25519 table); a table that
   // fits costs `table_penalty_cached`.  `force_window_tables` (tests) merges whenever possible.

@@ -453,8 +453,8 @@ def test_pipelined_calls(gpu_backend, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(got_a.cpu().numpy(), want) and np.array_equal(got_b.cpu().numpy(), want)
     lib.bzamd_generators_free(h)
-    # a random mix: deferred and plain calls, a five-column call (which ignores the request),
-    # flushes now and then; a result is read once something was enqueued after its call
+    # a random mix: deferred and plain calls, one and five columns, flushes now and then; a
+    # deferred result is read once something was enqueued after its call
     curve_id, d_gens = jobs[0][0], jobs[0][1]
     five = (api.sxt_sequence_descriptor * 5)()
     for c in range(5):
@@ -465,11 +465,12 @@ def test_pipelined_calls(gpu_backend, oracle):
         kind = int(rng.integers(0, 4))
         if kind == 3:
             out = torch.zeros((5, 32), dtype=torch.uint8, device=dev)
-            if rng.integers(0, 2):
+            deferred = bool(rng.integers(0, 2))
+            if deferred:
                 lib.bzamd_pipeline_next()
             lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 5, five,
                                  ctypes.c_void_p(d_gens.data_ptr()), stream)
-            want_k, deferred = want5, False
+            want_k = want5
         else:
             j = int(rng.integers(0, 4))
             out = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
