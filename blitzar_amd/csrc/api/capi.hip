@@ -30,6 +30,14 @@ namespace bz {
 std::atomic<u64> g_kernel_launches{0};
 
 namespace {
+// bzamd_pipeline_next: consumed by the next device entry point THIS THREAD calls -- never by an
+// engine call a blocking sxt_* function makes internally (those read their results right away)
+thread_local bool t_pipeline_next = false;
+void apply_pipeline_request(msm_context* ctx) {
+  if (!t_pipeline_next) return;
+  t_pipeline_next = false;
+  msm_context_defer_next_tail(ctx);
+}
 api_state* g_state = nullptr;
 
 api_state& state() {
@@ -725,6 +733,7 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
     BZ_HIP_CHECK(hipGetDevice(&dev));
     const resident_table* table = h.table_on(dev);
     BZ_RELEASE_ASSERT(table != nullptr, "the handle has no addends on the current device");
+    apply_pipeline_request(st.context_for_current_device());
     h.vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(res), out_stride, true,
                        cols, table->d_addends, caller_stream, table->tables());
     return;
@@ -1089,6 +1098,7 @@ void msm_device(unsigned curve_id, void* out, uint32_t num_sequences,
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
   checked_columns cc = check_descriptors(descriptors, num_sequences);
+  apply_pipeline_request(st.context_for_current_device());
   vt->msm(*st.context_for_current_device(), static_cast<u8*>(out),
           static_cast<u32>(projective_out ? vt->projective_size : vt->output_size), projective_out,
           cc.cols, nullptr, generators, static_cast<hipStream_t>(stream));
@@ -1098,7 +1108,7 @@ void msm_device(unsigned curve_id, void* out, uint32_t num_sequences,
 void bzamd_pipeline_next(void) {
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
-  msm_context_defer_next_tail(st.context_for_current_device());
+  t_pipeline_next = true;
 }
 
 void bzamd_pipeline_flush(void* stream) {
@@ -1194,6 +1204,7 @@ void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   BZ_RELEASE_ASSERT(cc.longest <= g->n, "sequence longer than the resident generator set");
+  apply_pipeline_request(st.context_for_current_device());
   g->vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(commitments),
                       static_cast<u32>(g->vt->output_size), false, cc.cols, g->table.d_addends,
                       static_cast<hipStream_t>(stream), g->table.tables());

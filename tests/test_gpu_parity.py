@@ -453,6 +453,15 @@ def test_pipelined_calls(gpu_backend, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(got_a.cpu().numpy(), want) and np.array_equal(got_b.cpu().numpy(), want)
     lib.bzamd_generators_free(h)
+    # a request is consumed by the next DEVICE entry point only: a blocking call in between reads
+    # its own results right away and must not be deferred
+    lib.bzamd_pipeline_next()
+    host_cols = [(rng.integers(0, 256, (3000, 32), dtype=np.uint8), False)]
+    host_gens = util.generators_for(0, 3000)
+    assert np.array_equal(
+        api.compute_pedersen_commitments(0, host_cols, generators=util.api_generators(0, host_gens)),
+        oracle.commit(0, host_cols, host_gens))
+    lib.bzamd_pipeline_flush(stream)
     # a random mix: deferred and plain calls, one and five columns, flushes now and then; a
     # deferred result is read once something was enqueued after its call
     curve_id, d_gens = jobs[0][0], jobs[0][1]
