@@ -121,7 +121,7 @@ BZ_HD ed29_point add_cached(const ed29_point& p, const ed29_cached& q, bool nega
   // -q = (Y-X, Y+X, Z, -2dT)
   const fe29 qa = f29::select(q.YpX, q.YmX, negate);
   const fe29 qb = f29::select(q.YmX, q.YpX, negate);
-  const fe29 qt = f29::select(q.T2d, f29::neg(q.T2d), negate); // B 2
+  const fe29 qt = f29::cneg_xad(q.T2d, negate);                // B 2
   const fe29 ypx = f29::add(p.Y, p.X);               // B 2
   const fe29 ymx = f29::sub(p.Y, p.X);               // B 3
   const fe29 a = f29::mul(ypx, qa);                  // 2 * 1
@@ -184,7 +184,7 @@ BZ_HD ed29_niels to_niels(const ed29_point& p) {
 BZ_HD ed29_point add_niels(const ed29_point& p, const ed29_niels& q, bool negate) {
   const fe29 qa = f29::select(q.YpX, q.YmX, negate);
   const fe29 qb = f29::select(q.YmX, q.YpX, negate);
-  const fe29 qt = f29::select(q.T2d, f29::neg(q.T2d), negate); // B 2
+  const fe29 qt = f29::cneg_xad(q.T2d, negate);                // B 2
   const fe29 a = f29::mul(f29::add(p.Y, p.X), qa);             // 2 * 1
   const fe29 b = f29::mul(f29::sub(p.Y, p.X), qb);             // 3 * 1
   const fe29 c = f29::mul(p.T, qt);                            // 1 * 2
