@@ -132,8 +132,10 @@ def timed_calls(lib, fn, steps, warmup, stream):
     """seconds per call of a sequence of `steps` calls in the library's throughput mode (the last
     stage of a call beside the front of the next, bzamd_pipeline_next), flushed inside the timed
     region; stage times from the same calls"""
-    for _ in range(warmup):
+    for _ in range(max(warmup, 2)):  # in the same mode: the engine sizes its workspace for it
+        lib.bzamd_pipeline_next()
         fn()
+    lib.bzamd_pipeline_flush(stream)
     torch.cuda.synchronize()
     clock = StageClock(lib, steps * 64)
     t0 = time.perf_counter()
