@@ -511,8 +511,10 @@ def main():
     if world == 1:
         handle = lib.bzamd_generators_new_device(curve_id, vp(generators), n, stream)
         out2 = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 2)):
+            lib.bzamd_pipeline_next()
             lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+        lib.bzamd_pipeline_flush(stream)
         torch.cuda.synchronize()
         clock2 = StageClock(lib, args.steps, ACCUMULATE_ONLY)
         t1 = time.perf_counter()
