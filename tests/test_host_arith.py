@@ -188,6 +188,12 @@ def test_planner_invariants():
     assert totals[6:].tolist() == [7, 3]
     per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256)
     assert totals[6:].tolist() == [7, 6] and per[0][0] == 16
+    # narrow columns: 256 (1 byte) or 1024 (4 bytes) buckets per task spread over the 256 lanes
+    # of their one reduce block, down to one bucket per lane
+    _, totals = hooks.plan([1 << 20], [8], [0])
+    assert totals[6:].tolist() == [5, 0]
+    _, totals = hooks.plan([1 << 20], [32], [0])
+    assert totals[6:].tolist() == [5, 2]
     # blocks of the bucket reduction stay full: 2^13 buckets per task leave 32 per lane
     per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256, max_window_bits=14)
     assert per[0][0] == 14 and totals[6:].tolist() == [7, 5]
