@@ -92,8 +92,9 @@ uint64_t bzamd_stage_timing_collect(double* out_ms);
  * otherwise simply waits); the caller's stream does not wait for them.  The commitments of such a
  * call are complete on `stream` only once a later such call on the device has been enqueued on
  * it, or after bzamd_pipeline_flush(stream): do not read them earlier.  Calls with 64 or more
- * columns ignore the request (their tails fill the machine).  One caller thread per device.
- * (Measured on MI355X, 2^20 rows: ~1.0 instead of 1.24 ms per call.) */
+ * columns ignore the request (their tails fill the machine).  A pipelined sequence lives on ONE
+ * stream (the join is enqueued on the stream of the later call, or of the flush) and one caller
+ * thread per device.  (Measured on MI355X, 2^20 rows: ~1.0 instead of 1.24 ms per call.) */
 void bzamd_pipeline_next(void);
 void bzamd_pipeline_flush(void* stream);
 
