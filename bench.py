@@ -39,6 +39,8 @@ from blitzar_amd import api  # noqa: E402
 import baseline_workloads as wl  # noqa: E402
 
 STAGES = ["prepare_addends", "recode", "bucket_sort", "accumulate", "reduce", "combine"]
+ACC_KERNEL = {0: "k_accumulate<bz::ed25519_msm>", 1: "k_accumulate<bz::bls12_381_msm>",
+              2: "k_accumulate<bz::bn254_msm>", 3: "k_accumulate<bz::grumpkin_msm>"}
 ACCUMULATE_ONLY = 1 << 3  # stage mask of bzamd_stage_timing_begin_masked
 HBM_PEAK_GBS = 8000.0
 # integer-ALU side of k_accumulate (the honest binding bound).  v_mad_u64_u32 per
@@ -46,7 +48,8 @@ HBM_PEAK_GBS = 8000.0
 # fold the eight high columns, as 64-bit sums, onto the low ones, 2 for the last carry).  Peak: the instruction issues once per 4 shader cycles per SIMD
 # (profiles/round2_valu_rates.txt: 4.5 against the 2.4 of a plain VALU op), 1024 SIMDs; the clock is
 # the effective shader clock the same micro-benchmark measures under an all-SIMD integer load.
-MADS_PER_ADDITION = {"cached": 792, "niels": 693}  # 8 (7) products x (81 + 17 + 1), ISA count
+# (per bucket addition: profiles/isa_counts.json, the count in the kernel's ISA -- curve25519: 8 field
+# products x (81 limb products + 17 that fold the eight high columns onto the low ones + 1))
 SIMDS = 1024
 MAD_ISSUE_CYCLES = 4.0
 EFFECTIVE_CLOCK_HZ = 2.1e9  # refined from profiles/alu_calibration.json when present
@@ -61,6 +64,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the reference-CPU leg (and with it the output verification)")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/4/5 legs")
+    ap.add_argument("--skip-headline-check", action="store_true",
+                    help="profiling runs: keep the oracle for the configs legs but skip the 16 s "
+                         "reference-CPU run on the headline column (no `verified`, no cpu_baseline)")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--dry-run-one-gpu", action="store_true",
                     help="self-test of the N > 1 control flow on a one-GPU box: every rank uses "
@@ -149,11 +155,54 @@ def timed_calls(lib, fn, steps, warmup, stream):
     return dt, stages
 
 
-def roofline_of(kernel, alg_bytes, accumulate_ms):
+def profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh)
+    return {}
+
+
+def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
+    """HBM roofline of the dominant kernel (algorithmic bytes over its HIP-event duration), plus --
+    from the committed rocprofv3 PMC passes of this command (profiles/roofline_traffic.json) and the
+    ISA counts of the kernel's loop (profiles/isa_counts.json) -- the HBM-side traffic per launch,
+    the fraction of cycles the SIMDs issued VALU work, and the integer-ALU side: v_mad_u64_u32
+    wave-instructions per second against the measured issue rate of that instruction."""
     achieved = alg_bytes / (accumulate_ms * 1e-3) / 1e9 if accumulate_ms > 0 else 0.0
-    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    roof = {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_call": alg_bytes, "kernel_ms_per_call": accumulate_ms}
+    pmc_all = profile_json("roofline_traffic.json") if use_pmc else {}
+    pmc = pmc_all.get("kernels", {}).get(kernel)
+    if pmc:
+        roof["traffic"] = pmc.get("bytes_per_launch")
+        roof["traffic_source"] = pmc_all.get("source")
+        roof["valu_busy"] = pmc.get("valu_busy")
+        roof["valu_wave_instructions_per_launch"] = pmc.get("sq_insts_valu_per_launch")
+    isa = profile_json("isa_counts.json").get("kernels", {}).get(kernel)
+    if isa and additions and accumulate_ms > 0:
+        cal = alu_calibration()
+        clock_hz = cal.get("effective_clock_hz", EFFECTIVE_CLOCK_HZ)
+        issue = cal.get("mad_u64_u32_cycles", MAD_ISSUE_CYCLES)
+        mads = isa["mads_per_addition"]
+        wave_mads = additions * mads / 64
+        peak = SIMDS * clock_hz / issue
+        dur_s = accumulate_ms * 1e-3
+        roof["alu"] = {"instruction": "v_mad_u64_u32", "per_addition": mads,
+                       "valu_instructions_per_addition_isa": isa["loop_valu"],
+                       "bucket_additions_per_launch": additions,
+                       "wave_instructions_per_launch": wave_mads,
+                       "achieved_per_s": wave_mads / dur_s, "peak_per_s": peak,
+                       "issue_cycles": issue, "effective_clock_hz": clock_hz,
+                       "frac": wave_mads / dur_s / peak,
+                       "ps_per_addition": dur_s / additions * 1e12,
+                       "source": "profiles/isa_counts.json (tools/prof/isa_count.py), "
+                                 "profiles/alu_calibration.json"}
+        if pmc and pmc.get("sq_insts_valu_per_launch"):
+            roof["alu"]["valu_instructions_per_addition_pmc"] = (
+                pmc["sq_insts_valu_per_launch"] * 64 / additions)
+    return roof
 
 
 #--------------------------------------------------------------------------------------------------
@@ -237,7 +286,9 @@ def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps,
              "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
              "verified": f"all {columns} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
                          "encoded by the reference's curve code",
-             "roofline": roofline_of(f"k_accumulate<curve {cid}>", alg_bytes, stages["accumulate"])}
+             # one bucket addition per non-zero digit: 252-bit scalars populate 16 windows of 16 bits
+             "roofline": roofline_of(ACC_KERNEL[cid], alg_bytes, stages["accumulate"],
+                                     additions=ops * 16)}
     # CPU sample: the reference backend on one column of 2^cpu_sample_log2n rows of this workload
     m = 1 << cpu_sample_log2n
     g_host = gens[:m].cpu().numpy()
@@ -302,7 +353,11 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
              "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
              "verified": f"all {outputs} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
                          "encoded by the reference's curve code",
-             "roofline": roofline_of("k_accumulate<grumpkin>", alg_bytes, stages["accumulate"])}
+             # bucket additions: one per signed 16-bit window of every field (1 / 3 / 16 for 8 / 32 /
+             # 256 bits; the 256-bit fields hold 252-bit values) and row
+             "roofline": roofline_of(ACC_KERNEL[cid], alg_bytes, stages["accumulate"],
+                                     additions=n * int(sum((min(int(b), 252) + 1 + 15) // 16
+                                                           for b in bit_table)))}
     # CPU sample: the reference's fixed-base path does not compile here (CUDA-only headers); its
     # variable-base CPU backend on one 8-, one 32- and one 256-bit output of 2^14 rows
     m = 1 << 14
@@ -430,6 +485,10 @@ def main():
 
     lib = api.load()
     assert api.init(api.SXT_GPU_BACKEND, 0) == 0
+    # a stream of the bench's own, not the NULL stream: the engine's throughput mode runs the stages
+    # of consecutive calls on internal streams, and every operation on the NULL stream implicitly
+    # waits for all blocking streams of the process (include/blitzar_amd.h, bzamd_pipeline_next)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     oracle = None if args.no_cpu_baseline else load_oracle()
 
@@ -544,7 +603,7 @@ def main():
     # CPU baseline
     cpu = None
     verified = None
-    if oracle is not None:
+    if oracle is not None and not args.skip_headline_check:
         gens_host = oracle.ristretto_generators(n)
         t2 = time.perf_counter()
         want = oracle.commit(0, [(scalars_host, False)], gens_host)
@@ -606,33 +665,13 @@ def main():
                                          f"stages: a separate untimed pass of {stage_steps} steps "
                                          "(every recorded stage costs two stream bubbles per call)")
             alg_bytes = n * (nbytes + gen_bytes)
-            dur_s = per_call["accumulate"] * 1e-3
-            roof = roofline_of("k_accumulate<ed25519>", alg_bytes, per_call["accumulate"])
-            roof["algorithmic_bytes_per_launch"] = alg_bytes
-            roof["kernel_ms"] = per_call["accumulate"]
-            # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command
-            # (tools/prof/run_pmc.sh -> profiles/roofline_traffic.json); null until collected
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-            if os.path.exists(tpath) and args.log2n is None:
-                with open(tpath) as fh:
-                    pmc = json.load(fh)
-                roof["traffic"] = pmc.get("k_accumulate_bytes_per_launch")
-                roof["traffic_source"] = pmc.get("source", "profiles/roofline_traffic.json")
-                roof["valu_busy"] = pmc.get("valu_busy")
-            cal = alu_calibration()
-            clock_hz = cal.get("effective_clock_hz", EFFECTIVE_CLOCK_HZ)
-            issue = cal.get("mad_u64_u32_cycles", MAD_ISSUE_CYCLES)
-            form = lib.bzamd_accumulate_form() if hasattr(lib, "bzamd_accumulate_form") else 0
-            mads = MADS_PER_ADDITION["niels" if form == 1 else "cached"]
             # one addition per non-zero digit: 252-bit scalars populate ceil(252 / 16) = 16 windows
             additions = n * ((8 * nbytes - (8 - top_mask.bit_length()) + 15) // 16)
-            wave_mads = additions * mads / 64
-            peak = SIMDS * clock_hz / issue
-            roof["alu"] = {"instruction": "v_mad_u64_u32", "per_addition": mads,
-                           "wave_instructions_per_launch": wave_mads,
-                           "achieved_per_s": wave_mads / dur_s, "peak_per_s": peak,
-                           "issue_cycles": issue, "effective_clock_hz": clock_hz,
-                           "frac": wave_mads / dur_s / peak}
+            # (the PMC passes were collected at the default shape: 2^20 rows)
+            roof = roofline_of(ACC_KERNEL[0], alg_bytes, per_call["accumulate"], additions=additions,
+                               use_pmc=args.log2n is None)
+            roof["algorithmic_bytes_per_launch"] = alg_bytes
+            roof["kernel_ms"] = per_call["accumulate"]
             result["roofline"] = roof
         if cpu is not None and world == 1:
             result["cpu_baseline"] = cpu

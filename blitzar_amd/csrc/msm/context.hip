@@ -53,10 +53,24 @@ msm_context* msm_context_new() {
   if (const char* v = std::getenv("BLITZAR_AMD_FORCE_WINDOW_TABLES")) {
     ctx->tuning.force_window_tables = v[0] != '0';
   }
-  if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_PREPARE")) ctx->overlap_prepare = v[0] != '0';
-  if (const char* v = std::getenv("BLITZAR_AMD_OVERLAP_TAILS")) ctx->overlap_tails = v[0] != '0';
-  if (const char* v = std::getenv("BLITZAR_AMD_TAIL_REDUCE")) ctx->tail_includes_reduce = v[0] != '0';
-  if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) ctx->two_tail_streams = v[0] != '1';
+  // throughput mode (engine.h, msm_context): "0" switches a feature off, anything else on
+  auto flag = [](const char* name, bool& out) {
+    if (const char* v = std::getenv(name)) out = !(v[0] == '0' && v[1] == 0);
+  };
+  flag("BLITZAR_AMD_OVERLAP_TAILS", ctx->overlap_tails);
+  flag("BLITZAR_AMD_OVERLAP_FRONT", ctx->overlap_front);
+  flag("BLITZAR_AMD_FRONT_PRIORITY", ctx->front_high_priority);
+  flag("BLITZAR_AMD_ACC_MASKED", ctx->acc_masked);
+  if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
+    const unsigned long streams = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");
+    ctx->two_tail_streams = streams == 2;
+  }
+  if (const char* v = std::getenv("BLITZAR_AMD_FRONT_CUS")) {
+    const unsigned long cus = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(cus <= 128, "BLITZAR_AMD_FRONT_CUS must be in [0, 128]");
+    ctx->front_cus = static_cast<u32>(cus);
+  }
 
   return ctx;
 }
@@ -89,7 +103,7 @@ void msm_context_defer_next_tail(msm_context* ctx) {
 }
 void msm_context_join_tail(msm_context* ctx, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(ctx->mu);
-  ctx->join_tail(stream);
+  ctx->join_all(stream);
 }
 void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask) {
   std::lock_guard<std::mutex> lock(ctx->mu);

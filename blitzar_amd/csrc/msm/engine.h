@@ -77,6 +77,29 @@ struct stage_timer {
   ~stage_timer() { release(); }
 };
 
+// A stage's completion mark: an event and the stream it was last recorded on.  A wait from the same
+// stream is implied by stream order and skipped (every record / wait is a packet in the queue).
+struct stage_mark {
+  hipEvent_t ev = nullptr;
+  hipStream_t on = nullptr;
+  bool set = false;
+  void record(hipStream_t stream) {
+    if (ev == nullptr) BZ_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    BZ_HIP_CHECK(hipEventRecord(ev, stream));
+    on = stream;
+    set = true;
+  }
+  void wait(hipStream_t stream) const {
+    if (!set || stream == on) return;
+    BZ_HIP_CHECK(hipStreamWaitEvent(stream, ev, 0));
+  }
+  void destroy() {
+    if (ev != nullptr) (void)hipEventDestroy(ev);
+    ev = nullptr;
+    set = false;
+  }
+};
+
 // One context per device: the workspace arena, the pinned descriptor ring and the stage timer are
 // shared by every MSM call enqueued on that device.  Calls are asynchronous on a caller stream, so
 // two things keep them from trampling each other's workspace:
@@ -84,7 +107,7 @@ struct stage_timer {
 //   * a call arriving on a DIFFERENT stream than the previous one first makes its stream wait for
 //     everything enqueued on the previous stream (`order_after_previous`) -- calls on one device
 //     therefore execute one after the other whatever streams they come in on; what does overlap
-//     is the tail of a call with the call after it, on the context's own tail stream (below).
+//     are the stages of consecutive calls of a pipelined sequence (throughput mode, below).
 struct msm_context {
   device_arena arena;
   host_stage_ring descriptors; // pinned copies of the column / task descriptors in flight
@@ -95,69 +118,107 @@ struct msm_context {
   hipStream_t last_stream = nullptr;
   bool has_last = false;
   bool kernels_configured = false; // hipFuncSetAttribute applies to the device current at the call
-  // side stream of a call: the conversion of caller generators (k_prepare_addends*: latency-bound
-  // when it shares inversions) runs beside the recoding and sorting of the scalars, which do not
-  // depend on it; joined before k_accumulate
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
   // Device copies of the descriptors (columns | tasks | packed-recode ranges) in blocks of their
-  // own -- two, one per tail set (below; plain calls use block 0) -- and `desc_shadow` = the bytes
-  // each holds.  A batch whose descriptors are byte-identical to its block's -- the same shapes
-  // over the same device pointers: a caller committing again and again from the same buffers --
-  // skips the pinned staging, the H2D copy and the two stream bubbles around it (~15 us of a 1.3 ms
-  // call).  Only msm_enqueue_batch writes a block, on the stream of the call and after the tail
-  // that read it last has been joined; calls on one context are ordered (order_after_previous).
-  // Tail stream.  The two stages after k_accumulate are latency chains that leave the machine
-  // nearly idle: k_reduce runs one wavefront per SIMD, k_horner ONE workgroup per column (~250
-  // dependent doublings and the encoding's 250 squarings); together 0.39 of a 1.24 ms call at
-  // config 2.  In throughput mode they are enqueued on a stream of their own and run beside
-  // whatever the caller's stream does next on this context: the generator conversion, recoding
-  // and sorting of the next batch or call, and the start of its accumulation.  What the tail reads
-  // and the next front writes -- bucket ends, bucket sums, head partials, partials, task totals --
-  // then exists twice, and consecutive calls alternate (`tail_parity`); a call waits for the tail
-  // that used its set two calls ago (`tail_done[parity]`) before its sort rewrites the bucket ends.
-  // That only works while consecutive calls carve the arena identically (same shapes, same curve,
-  // same mode: `tail_layout`); any other call first joins every pending tail (`join_tail`), and so
-  // does a re-allocation of the arena, the end of a call that is not deferred, and
-  // bzamd_pipeline_flush; a descriptor block is rewritten after the tail that read it was joined.  Used across calls issued through bzamd_pipeline_next
-  // (whose results are complete on the caller's stream only after a later call or a flush); any
-  // other call keeps everything on the caller's stream -- plain stream semantics, and forking
-  // would only add stream bubbles (measured: 1.237 -> 1.266 ms at config 2).  The tail kernels
-  // raise their wave priority (s_setprio): beside a k_accumulate that owns every SIMD they would
-  // otherwise crawl (config 3: k_horner 1.3 -> 6.7 ms) and become the pipeline's bottleneck.
-  // (Two tail streams: k_horner of call i on the second one, so that it also runs beside k_reduce of
-  // call i + 1 -- the tails of a sequence then cost max(reduce, horner) per call instead of their
-  // sum, which matters on the pool's slower kind of box, where they add up to more than the front
-  // and the accumulation of a call; on the faster kind 1.037 -> 1.025 ms per call.)
-  hipStream_t tail = nullptr, tail2 = nullptr;
-  hipEvent_t tail_fork = nullptr, tail_mid = nullptr;
-  hipEvent_t tail_done[2] = {nullptr, nullptr};
-  bool tail_pending[2] = {false, false};
-  u32 tail_parity = 0;
-  u64 tail_layout = 0;        // layout tag of the calls whose tails are pending
-  bool defer_tail = false;    // the next call leaves its tail pending (msm_context_defer_next_tail)
+  // own -- two, one per buffer set of the throughput mode (plain calls use block 0) -- and
+  // `desc_shadow` = the bytes each holds.  A batch whose descriptors are byte-identical to its
+  // block's -- the same shapes over the same device pointers: a caller committing again and again
+  // from the same buffers -- skips the pinned staging, the H2D copy and the two stream bubbles
+  // around it (~15 us of a 1.3 ms call).  Only msm_enqueue_batch writes a block, after the last
+  // stage that read it (k_horner, two batches ago) has finished.
+  //
+  // Throughput mode (bzamd_pipeline_next; batch = one launch sequence, a call of a few columns is
+  // one batch).  A batch has four stages with complementary bottlenecks:
+  //   front      conversion of caller generators, recoding, the two-pass bucket sort: nine short
+  //              HBM-bound kernels (0.2-0.3 ms at 2^20 curve25519 rows, ~0.64 GB moved);
+  //   accumulate the bucket additions: integer-issue bound, every SIMD full (0.7 ms);
+  //   reduce     bucket reduction: a latency chain at one wavefront per SIMD (0.2-0.3 ms);
+  //   horner     ONE workgroup per column, ~250 dependent doublings + the encoding (0.2-0.4 ms).
+  // In a sequence of same-shaped calls every stage gets a stream of its own and batch k + 1's front
+  // runs beside batch k's accumulation, whose reduce and horner run beside batch k + 1's
+  // accumulation: a step then costs about max(stage) instead of their sum.  The buffers a stage
+  // writes while an earlier batch's later stage still reads exist more than once, indexed by the
+  // batch's sequence number: everything the front writes and the accumulation reads (addends,
+  // digits, records, sorted entries, group tables, segment map) twice; the bucket ends (written by
+  // the sort, read by accumulate AND reduce) three times; what accumulate / reduce / horner hand
+  // on (bucket sums, head partials, partials, entry counts, chain state) twice.  Completion marks
+  // (rings of 4 events) order a stage behind the stage of an earlier batch whose buffers it reuses.
+  //   * The caller's stream only carries waits: at entry the front stream waits for it (the
+  //     operands are ready), at the end of the call it waits for the batch's front (the operands
+  //     have been consumed: the caller may overwrite them in stream order) and for the PREVIOUS
+  //     batch's horner, so a result is complete on the stream once the next call has been enqueued
+  //     or after bzamd_pipeline_flush.
+  //   * k_accumulate owns every SIMD's registers (3 waves x 168 VGPRs), so kernels of another
+  //     stream only get a slot when one of its workgroups retires, and the sort's 1024-lane
+  //     workgroups need a whole CU's worth at once: the front stream and the accumulation stream
+  //     therefore get disjoint CU masks (`front_cus` CUs for the front, spread evenly over the 8
+  //     XCDs: KFD deals mask bit i to XCC i mod 8); the two tail kernels are single-wave-per-SIMD
+  //     workgroups that slot in anywhere and raise their wave priority (s_setprio).
+  //   * Only while consecutive batches carve the arena identically (same shapes, curve, mode:
+  //     `pipe_layout`); any other call first joins everything pending, and so does a re-allocation
+  //     of the arena, a call outside the mode and bzamd_pipeline_flush.
+  // BLITZAR_AMD_OVERLAP_FRONT=0 keeps front and accumulation on the caller's stream (round 2's
+  // form: only the tails overlap); BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.
+  // A lone call never forks (every fork / join pair costs ~25 us of stream bubbles).
+  hipStream_t front = nullptr, acc = nullptr, tail = nullptr, tail2 = nullptr;
+  bool pipe_streams_made = false;
+  stage_mark entry;
+  stage_mark front_done[4], acc_done[4], reduce_done[4], horner_done[4];
+  u64 seq = 0;            // pipelined batches enqueued so far on this context
+  u64 joined = 0;         // the caller's stream `joined_on` has waited for every batch below this
+  hipStream_t joined_on = nullptr;
+  u64 pipe_layout = 0;        // layout tag of the pending batches
+  bool defer_tail = false;    // the next call runs in throughput mode (msm_context_defer_next_tail)
   bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: never fork
-  bool tail_includes_reduce = true; // BLITZAR_AMD_TAIL_REDUCE=0: only k_horner forks
-  bool two_tail_streams = true;     // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
-  hipStream_t tail_stream() {
-    if (tail == nullptr) {
-      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
-      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail2, hipStreamNonBlocking));
-      BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_fork, hipEventDisableTiming));
-      BZ_HIP_CHECK(hipEventCreateWithFlags(&tail_mid, hipEventDisableTiming));
-      for (auto& e : tail_done) BZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  bool overlap_front = true;  // BLITZAR_AMD_OVERLAP_FRONT=0: front + accumulation on the caller's stream
+  bool two_tail_streams = true; // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
+  u32 front_cus = 32;         // BLITZAR_AMD_FRONT_CUS: CUs reserved for the front stream (0: no masks)
+  bool front_high_priority = false; // BLITZAR_AMD_FRONT_PRIORITY=1 (without masks): a high-priority queue
+  bool acc_masked = true;     // BLITZAR_AMD_ACC_MASKED=0: the accumulation may also use the front's CUs
+  void make_pipe_streams() {
+    if (pipe_streams_made) return;
+    pipe_streams_made = true;
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail2, hipStreamNonBlocking));
+    if (!overlap_front) return;
+    int device = 0, cus = 0;
+    BZ_HIP_CHECK(hipGetDevice(&device));
+    BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (front_cus != 0 && cus >= 64 && front_cus * 2 <= static_cast<u32>(cus)) {
+      // mask bit i -> XCC i mod 8 (kfd mqd_symmetrically_map_cu_mask): a contiguous range of
+      // bits is spread evenly over the XCDs
+      const u32 words = (static_cast<u32>(cus) + 31) / 32;
+      std::vector<uint32_t> fm(words, 0), am(words, 0);
+      const u32 split = static_cast<u32>(cus) - front_cus;
+      for (u32 i = 0; i < static_cast<u32>(cus); ++i) {
+        (i >= split ? fm : am)[i / 32] |= 1u << (i % 32);
+        if (!acc_masked) am[i / 32] |= 1u << (i % 32);
+      }
+      if (hipExtStreamCreateWithCUMask(&front, words, fm.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&acc, words, am.data()) == hipSuccess) {
+        return;
+      }
+      (void)hipGetLastError();
+      std::fprintf(stderr, "blitzar_amd: CU-masked streams unavailable, using plain streams\n");
+      if (front != nullptr) (void)hipStreamDestroy(front);
+      front = acc = nullptr;
     }
-    return tail;
+    if (front_high_priority) {
+      int least = 0, greatest = 0;
+      BZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      BZ_HIP_CHECK(hipStreamCreateWithPriority(&front, hipStreamNonBlocking, greatest));
+    } else {
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&front, hipStreamNonBlocking));
+    }
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&acc, hipStreamNonBlocking));
   }
-  bool any_tail_pending() const { return tail_pending[0] || tail_pending[1]; }
-  void join_tail(hipStream_t stream, u32 parity) {
-    if (!tail_pending[parity]) return;
-    BZ_HIP_CHECK(hipStreamWaitEvent(stream, tail_done[parity], 0));
-    tail_pending[parity] = false;
-  }
-  void join_tail(hipStream_t stream) {
-    join_tail(stream, 0);
-    join_tail(stream, 1);
+  bool any_pending() const { return joined < seq; }
+  // make `stream` wait for every pipelined batch enqueued so far (k_horner runs on ONE stream, in
+  // order, and is the last stage of a batch: the last batch's mark covers everything)
+  void join_all(hipStream_t stream) {
+    if (seq == 0 || (joined == seq && stream == joined_on)) return;
+    horner_done[(seq - 1) & 3].wait(stream);
+    joined = seq;
+    joined_on = stream;
   }
   char* desc_dev[2] = {nullptr, nullptr};
   size_t desc_cap[2] = {0, 0};
@@ -172,30 +233,21 @@ struct msm_context {
     }
     return desc_dev[which];
   }
-  bool overlap_prepare = false; // BLITZAR_AMD_OVERLAP_PREPARE=1 (no gain for the HBM-bound per-point conversion)
   ~msm_context() {
     if (last_done != nullptr) (void)hipEventDestroy(last_done);
-    if (fork != nullptr) (void)hipEventDestroy(fork);
-    if (join != nullptr) (void)hipEventDestroy(join);
-    if (side != nullptr) (void)hipStreamDestroy(side);
     for (auto& d : desc_dev) {
       if (d != nullptr) (void)hipFree(d);
     }
-    if (tail_fork != nullptr) (void)hipEventDestroy(tail_fork);
-    if (tail_mid != nullptr) (void)hipEventDestroy(tail_mid);
-    if (tail2 != nullptr) (void)hipStreamDestroy(tail2);
-    for (auto& e : tail_done) {
-      if (e != nullptr) (void)hipEventDestroy(e);
+    entry.destroy();
+    for (int i = 0; i < 4; ++i) {
+      front_done[i].destroy();
+      acc_done[i].destroy();
+      reduce_done[i].destroy();
+      horner_done[i].destroy();
     }
-    if (tail != nullptr) (void)hipStreamDestroy(tail);
-  }
-  hipStream_t side_stream() {
-    if (side == nullptr) {
-      BZ_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      BZ_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-      BZ_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    for (hipStream_t s : {front, acc, tail2, tail}) {
+      if (s != nullptr) (void)hipStreamDestroy(s);
     }
-    return side;
   }
   // order `stream` behind the previous call on this context (no-op on the same stream).  The event
   // is recorded only now, on the previous call's stream -- behind that call and whatever the caller
@@ -235,31 +287,41 @@ static void configure_sort_kernels(msm_context& ctx) {
   ctx.kernels_configured = true;
 }
 
+// buffer sets of a batch (msm_context: throughput mode)
+struct pipe_mode {
+  bool piped = false; // reduce + horner on the tail streams
+  bool split = false; // ... and front / accumulation on streams of their own
+  u32 front_sets() const { return split ? 2 : 1; }
+  u32 end_sets() const { return split ? 3 : (piped ? 2 : 1); }
+  u32 tail_sets() const { return piped ? 2 : 1; }
+};
+
 // device workspace of one batch of columns (everything carved from the arena)
 template <class C>
 size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial_stride,
-                           bool two_tail_sets = false) {
+                           pipe_mode mode = {}) {
   using point = typename C::point;
   using addend = typename C::addend;
   const size_t num_tasks = plan.tasks.size(), num_cols = plan.columns.size();
-  size_t need = 0;
   // (the descriptors live in a block of their own: msm_context::descriptor_block)
-  if (needs_addends) need += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
-  need += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
-  need += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
-  need += 3 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
-  need += device_arena::padded(sizeof(u32) * (num_tasks + 1));
-  need += device_arena::padded(sizeof(u32) * 2 * (plan.total_buckets + 1));
-  need += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
-  // what the tail stages read (msm_context::tail): twice in throughput mode
+  // what the front writes and the accumulation reads
+  size_t front = 0;
+  if (needs_addends) front += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
+  front += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
+  front += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
+  front += 3 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
+  front += device_arena::padded(sizeof(u32) * (num_tasks + 1));
+  front += device_arena::padded(sizeof(u32) * 2 * (plan.total_buckets + 1));
+  front += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
+  const size_t ends = device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
+  // what accumulate, reduce and horner hand on
   size_t tail = 0;
-  tail += device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
   tail += device_arena::padded(sizeof(point) * (plan.total_buckets + 1));
   tail += device_arena::padded(sizeof(point) * (plan.total_segments + 1));
   tail += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
   tail += device_arena::padded(sizeof(point) * (num_cols + 1));
   tail += device_arena::padded(sizeof(u32) * (num_tasks + 1));
-  return need + (two_tail_sets ? 2 : 1) * tail;
+  return mode.front_sets() * front + mode.end_sets() * ends + mode.tail_sets() * tail;
 }
 
 static inline u32 partial_stride_of(const msm_plan& plan) {
@@ -269,7 +331,7 @@ static inline u32 partial_stride_of(const msm_plan& plan) {
 template <class C>
 void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const msm_plan& plan, const typename C::addend* d_addends,
-                       const void* d_api_generators, hipStream_t stream, bool tail_on_side);
+                       const void* d_api_generators, hipStream_t stream, pipe_mode mode);
 
 // Enqueue the MSM.  `d_addends` covers rows [0, max n); `d_out` receives one encoding per column
 // (`out_stride` bytes apart): canonical (`C::encode`) or raw projective when `projective_out`.
@@ -290,8 +352,9 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   // and completes on the caller's stream
   size_t nonempty_columns = 0;
   for (const auto& c : cols) nonempty_columns += c.n != 0 ? 1 : 0;
-  const bool defer_tail = ctx.defer_tail && ctx.overlap_tails &&
-                          nonempty_columns < ctx.tuning.defer_max_columns;
+  pipe_mode mode;
+  mode.piped = ctx.defer_tail && ctx.overlap_tails && nonempty_columns < ctx.tuning.defer_max_columns;
+  mode.split = mode.piped && ctx.overlap_front;
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   bool any_signed = false;
@@ -311,11 +374,10 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   std::vector<size_t> first_column;
   size_t need = 0;
   const bool needs_addends = d_addends == nullptr;
-  bool two_tail_sets = false;
   auto plan_range = [&](size_t begin, size_t end, size_t& bytes) {
     msm_plan p = make_msm_plan(std::vector<host_column>(cols.begin() + begin, cols.begin() + end),
                                tune, tables);
-    bytes = msm_workspace_bytes<C>(p, needs_addends, partial_stride_of(p), two_tail_sets);
+    bytes = msm_workspace_bytes<C>(p, needs_addends, partial_stride_of(p), mode);
     return p;
   };
   auto fits = [&](const msm_plan& p, size_t bytes) {
@@ -323,52 +385,48 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     return p.tasks.size() <= tune.max_tasks_per_batch && p.columns.size() <= 32768 &&
            bytes <= tune.max_workspace_bytes;
   };
-  auto cut_batches = [&] {
-    batches.clear();
-    first_column.clear();
-    need = 0;
-    for (size_t begin = 0; begin < cols.size();) {
-      size_t bytes = 0;
-      size_t end = cols.size();
-      msm_plan plan = plan_range(begin, end, bytes);
-      if (!fits(plan, bytes) && end - begin > 1) {
-        size_t lo = begin + 1, hi = end; // [begin, lo) is accepted, [begin, hi) is known not to fit
-        plan = plan_range(begin, lo, bytes);
-        while (hi - lo > 1) {
-          const size_t mid = lo + (hi - lo) / 2;
-          size_t mid_bytes = 0;
-          msm_plan p = plan_range(begin, mid, mid_bytes);
-          if (fits(p, mid_bytes)) {
-            plan = std::move(p);
-            bytes = mid_bytes;
-            lo = mid;
-          } else {
-            hi = mid;
-          }
+  for (size_t begin = 0; begin < cols.size();) {
+    size_t bytes = 0;
+    size_t end = cols.size();
+    msm_plan plan = plan_range(begin, end, bytes);
+    if (!fits(plan, bytes) && end - begin > 1) {
+      size_t lo = begin + 1, hi = end; // [begin, lo) is accepted, [begin, hi) is known not to fit
+      plan = plan_range(begin, lo, bytes);
+      while (hi - lo > 1) {
+        const size_t mid = lo + (hi - lo) / 2;
+        size_t mid_bytes = 0;
+        msm_plan p = plan_range(begin, mid, mid_bytes);
+        if (fits(p, mid_bytes)) {
+          plan = std::move(p);
+          bytes = mid_bytes;
+          lo = mid;
+        } else {
+          hi = mid;
         }
-        end = lo;
       }
-      if (bytes > need) need = bytes;
-      first_column.push_back(begin);
-      batches.push_back(std::move(plan));
-      begin = end;
+      end = lo;
     }
-  };
-  // a deferred call runs its tail stages beside the front of the next call (msm_context::tail);
-  // that mode keeps two sets of the tail's buffers
-  two_tail_sets = defer_tail;
-  cut_batches();
-  const bool tail_on_side = two_tail_sets;
+    if (bytes > need) need = bytes;
+    first_column.push_back(begin);
+    batches.push_back(std::move(plan));
+    begin = end;
+  }
+  if (mode.piped) ctx.make_pipe_streams();
+  // a call outside the mode uses buffer set 0 on the caller's stream: everything pending first
+  if (!mode.piped) ctx.join_all(stream);
   // one allocation sized for the largest batch: later resets never reallocate (no mid-call sync)
-  if (need > ctx.arena.capacity()) ctx.join_tail(stream); // the arena is about to be re-allocated
+  if (need > ctx.arena.capacity()) ctx.join_all(stream); // the arena is about to be re-allocated
   ctx.arena.reset(need, stream);
+  // the front stream starts behind whatever the caller's stream holds now (operands ready)
+  if (mode.split) ctx.entry.record(stream);
   for (size_t k = 0; k < batches.size(); ++k) {
     ctx.arena.reset(need, stream);
     msm_enqueue_batch<C>(ctx, d_out + first_column[k] * static_cast<size_t>(out_stride), out_stride,
-                         projective_out, batches[k], d_addends, d_api_generators, stream,
-                         tail_on_side);
+                         projective_out, batches[k], d_addends, d_api_generators, stream, mode);
   }
-  if (!defer_tail) ctx.join_tail(stream);
+  // the operands have been consumed once the last front is through: the caller may overwrite
+  // them in stream order
+  if (mode.split && ctx.seq != 0) ctx.front_done[(ctx.seq - 1) & 3].wait(stream);
   ctx.mark_enqueued(stream);
 }
 
@@ -398,7 +456,7 @@ template <class C> struct batch_buffers {
 template <class C>
 void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                        const msm_plan& plan, const typename C::addend* d_addends,
-                       const void* d_api_generators, hipStream_t stream, bool tail_on_side) {
+                       const void* d_api_generators, hipStream_t stream, pipe_mode mode) {
   using point = typename C::point;
   using addend = typename C::addend;
   const u32 num_tasks = static_cast<u32>(plan.tasks.size());
@@ -426,7 +484,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     std::memcpy(image.data() + col_bytes + task_bytes, ranges.data(),
                 sizeof(recode_range) * ranges.size());
   }
-  // pending tails were carved from the arena exactly like this batch (every size that enters the
+  // pending batches were carved from the arena exactly like this one (every size that enters the
   // carving below, the curve and the mode), or they go first
   u64 layout = 0xcbf29ce484222325ull;
   for (u64 v : {static_cast<u64>(plan.total_entries), static_cast<u64>(plan.total_groups),
@@ -434,19 +492,37 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                 static_cast<u64>(plan.max_rows), static_cast<u64>(num_tasks),
                 static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
                 static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
-                static_cast<u64>(d_addends == nullptr), static_cast<u64>(tail_on_side)}) {
+                static_cast<u64>(d_addends == nullptr),
+                static_cast<u64>(mode.piped) | static_cast<u64>(mode.split) << 1}) {
     layout = (layout ^ v) * 0x100000001b3ull;
   }
-  if (ctx.any_tail_pending() && layout != ctx.tail_layout) ctx.join_tail(stream);
-  // this batch's tail set and descriptor block (plain calls: set 0)
-  const u32 parity = tail_on_side ? ctx.tail_parity : 0;
+  if (ctx.any_pending() && layout != ctx.pipe_layout) {
+    ctx.join_all(stream);
+    if (mode.split) ctx.entry.record(stream); // the front stream starts behind the join
+  }
+  // this batch's place in the sequence, its buffer sets, its streams
+  const u64 k = ctx.seq;
+  const u32 parity = mode.piped ? static_cast<u32>(k & 1) : 0;
+  const u32 end_set = mode.piped ? static_cast<u32>(k % mode.end_sets()) : 0;
+  hipStream_t fs = mode.split ? ctx.front : stream;
+  hipStream_t as = mode.split ? ctx.acc : stream;
+  hipStream_t rs = mode.piped ? ctx.tail : stream;
+  hipStream_t hs = mode.piped ? (ctx.two_tail_streams ? ctx.tail2 : ctx.tail) : stream;
+  // completion marks of earlier batches (none outside the mode: join_all came first)
+  auto earlier = [&](stage_mark* ring, u64 back) -> const stage_mark* {
+    return mode.piped && k >= back ? &ring[(k - back) & 3] : nullptr;
+  };
+  auto wait_for = [](const stage_mark* m, hipStream_t s) {
+    if (m != nullptr) m->wait(s);
+  };
+  if (mode.split) ctx.entry.wait(fs);
   char* desc = ctx.descriptor_block(parity, desc_bytes);
   if (image != ctx.desc_shadow[parity]) {
-    ctx.join_tail(stream, parity); // the tail that read this block two batches ago
+    wait_for(earlier(ctx.horner_done, 2), fs); // the last reader of this block
     char* staged = static_cast<char*>(ctx.descriptors.acquire(desc_bytes));
     std::memcpy(staged, image.data(), desc_bytes);
-    BZ_HIP_CHECK(hipMemcpyAsync(desc, staged, desc_bytes, hipMemcpyHostToDevice, stream));
-    ctx.descriptors.release(stream);
+    BZ_HIP_CHECK(hipMemcpyAsync(desc, staged, desc_bytes, hipMemcpyHostToDevice, fs));
+    ctx.descriptors.release(fs);
     ctx.desc_shadow[parity] = image;
   }
   b.cols = reinterpret_cast<column_desc*>(desc);
@@ -454,53 +530,66 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   recode_range* d_ranges =
       ranges.empty() ? nullptr : reinterpret_cast<recode_range*>(desc + col_bytes + task_bytes);
   if (num_tasks == 0) {
-    // every column is empty: identities only
-    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, stream, d_out,
+    // every column is empty: identities only, on the stream that carries every k_horner (in order
+    // behind the previous batch's), behind the descriptor upload
+    if (mode.piped) {
+      ctx.front_done[k & 3].record(fs);
+      ctx.front_done[k & 3].wait(hs);
+    }
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                        out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
                        static_cast<const point*>(nullptr), 1u, b.cols,
                        static_cast<const task_desc*>(nullptr), static_cast<const u32*>(nullptr), 0u,
                        0u, 1, 1, plan.reduce_segment_log2);
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipGetLastError());
+    if (mode.piped) {
+      // keeps its place in the sequence: every mark of the slot points behind this launch
+      ctx.acc_done[k & 3].record(hs);
+      ctx.reduce_done[k & 3].record(hs);
+      ctx.horner_done[k & 3].record(hs);
+      ctx.pipe_layout = layout;
+      ctx.seq = k + 1;
+    }
     return;
   }
   const bool timing = ctx.timer.recording();
-  bool join_prepare = false;
-  if (d_addends == nullptr) {
-    addend* prepared = ctx.arena.take<addend>(plan.max_rows + 1);
-    hipStream_t where = stream;
-    if (ctx.overlap_prepare) {
-      where = ctx.side_stream();
-      BZ_HIP_CHECK(hipEventRecord(ctx.fork, stream));
-      BZ_HIP_CHECK(hipStreamWaitEvent(where, ctx.fork, 0));
-      join_prepare = true;
+  // carve the arena: the same walk for every batch of a layout, this batch's sets picked out
+  for (u32 set = 0; set < mode.front_sets(); ++set) {
+    addend* prepared = d_addends == nullptr ? ctx.arena.take<addend>(plan.max_rows + 1) : nullptr;
+    i16* digits = ctx.arena.take<i16>(plan.total_entries + 8);
+    u32* records = ctx.arena.take<u32>(plan.total_entries + 8);
+    u32* sorted = ctx.arena.take<u32>(plan.total_entries + 8);
+    u32* group_cursor = ctx.arena.take<u32>(plan.total_groups + 1);
+    u32* group_start = ctx.arena.take<u32>(plan.total_groups + 1);
+    u32* group_chunk = ctx.arena.take<u32>(plan.total_groups + 1);
+    u32* big_tasks = ctx.arena.take<u32>(num_tasks + 1);
+    u32* bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
+    u32* segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
+    if (set == (mode.split ? parity : 0)) {
+      b.addends = d_addends == nullptr ? prepared : d_addends;
+      b.digits = digits;
+      b.records = records;
+      b.sorted = sorted;
+      b.group_cursor = group_cursor;
+      b.group_start = group_start;
+      b.group_chunk = group_chunk;
+      b.big_tasks = big_tasks;
+      b.bucket_count = bucket_count;
+      b.segment_bucket = segment_bucket;
     }
-    ctx.timer.timed(timing, 0, where, [&] {
-      launch_prepare_addends<C>(prepared, d_api_generators, plan.max_rows, where);
-    });
-    if (join_prepare) BZ_HIP_CHECK(hipEventRecord(ctx.join, where));
-    d_addends = prepared;
   }
-  b.addends = d_addends;
-  b.digits = ctx.arena.take<i16>(plan.total_entries + 8);
-  b.records = ctx.arena.take<u32>(plan.total_entries + 8);
-  b.sorted = ctx.arena.take<u32>(plan.total_entries + 8);
-  b.group_cursor = ctx.arena.take<u32>(plan.total_groups + 1);
-  b.group_start = ctx.arena.take<u32>(plan.total_groups + 1);
-  b.group_chunk = ctx.arena.take<u32>(plan.total_groups + 1);
-  b.big_tasks = ctx.arena.take<u32>(num_tasks + 1);
-  b.bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
-  b.segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
-  // what the tail stages read: two sets in throughput mode, this batch uses set `parity`
-  for (u32 set = 0; set < (tail_on_side ? 2u : 1u); ++set) {
+  for (u32 set = 0; set < mode.end_sets(); ++set) {
     u32* bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
+    if (set == end_set) b.bucket_end = bucket_end;
+  }
+  for (u32 set = 0; set < mode.tail_sets(); ++set) {
     point* bucket_sums = ctx.arena.take<point>(plan.total_buckets + 1);
     point* heads = ctx.arena.take<point>(plan.total_segments + 1);
     point* partials = ctx.arena.take<point>(static_cast<size_t>(num_tasks) * b.partial_stride + 1);
     point* horner_state = ctx.arena.take<point>(num_cols);
     u32* task_total = ctx.arena.take<u32>(num_tasks + 1);
     if (set == parity) {
-      b.bucket_end = bucket_end;
       b.bucket_sums = bucket_sums;
       b.heads = heads;
       b.partials = partials;
@@ -512,20 +601,25 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   const u32 seg_blocks =
       ceil_div_u32(plan.max_task_rows, static_cast<u64>(kAccumulateThreads) << plan.segment_log2);
 
-  // One stream, stages in order.  (Running the sort of window group k+1 and the reduce / Horner of
-  // group k-1 on side streams under the accumulation of group k was measured on MI355X and is
-  // slower, 1.94 -> 2.0-2.3 ms at config 2: k_accumulate's waves hold 480 of a SIMD's 512 VGPRs,
-  // so side kernels only get slots as accumulate waves retire and both sides lose.  A second
-  // attempt -- two window groups, the high group's reduce + Horner on a highest-priority stream
-  // beside the low group's accumulation, that launch held to two workgroups per CU with unused
-  // dynamic LDS so registers stay free -- still queued the side kernels behind the accumulation:
-  // 1.74 -> 1.87 ms.)
+  // ---- front: on the caller's stream, or (throughput mode) beside the previous batch's
+  // accumulation on the front stream.  Its buffers were last read by the accumulation two batches
+  // ago, the bucket ends it rewrites by the reduce `end_sets` batches ago.
+  // (Overlapping stages of ONE call was measured in round 1 and is slower: k_accumulate's waves
+  // hold 480 of a SIMD's 512 VGPRs, side kernels only get slots as they retire, and everything a
+  // call runs feeds its next stage.)
+  wait_for(earlier(ctx.acc_done, 2), fs);
+  wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
+  if (d_addends == nullptr) {
+    ctx.timer.timed(timing, 0, fs, [&] {
+      launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
+    });
+  }
   const u64 zero_words = plan.total_groups + 1; // group cursors, cleared by the recode kernel
-  ctx.timer.timed(timing, 1, stream, [&] {
+  ctx.timer.timed(timing, 1, fs, [&] {
     if (d_ranges != nullptr) {
       hipLaunchKernelGGL(k_recode_packed,
                          dim3(ceil_div_u32(plan.max_recode_rows, kPackedTileRows)),
-                         dim3(kPackedRecodeThreads), kPackedTileBytes, stream, b.digits, b.cols,
+                         dim3(kPackedRecodeThreads), kPackedTileBytes, fs, b.digits, b.cols,
                          b.tasks, d_ranges, static_cast<u32>(ranges.size()),
                          plan.columns[0].row_stride, plan.max_recode_rows, plan.max_rows,
                          b.group_cursor, zero_words);
@@ -534,82 +628,83 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
     const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
     const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
-    hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, stream, b.digits, b.cols,
+    hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, fs, b.digits, b.cols,
                        b.tasks, num_cols, chunks, b.group_cursor, zero_words);
   });
-  ctx.join_tail(stream, parity); // (joined at the end of the previous batch already)
-  ctx.timer.timed(timing, 2, stream, [&] {
+  ctx.timer.timed(timing, 2, fs, [&] {
     hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       part_lds, stream, b.group_cursor, b.big_tasks, b.digits, b.tasks);
+                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks);
     u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
-    hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, stream, b.group_cursor,
+    hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, fs, b.group_cursor,
                        b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
                        b.tasks);
     // all tasks of a launch share one variant: staged unless some column needs the direct form
     if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
       const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
       hipLaunchKernelGGL(k_group_scatter<true>, dim3(plan.max_task_slices, num_tasks),
-                         dim3(kSortThreads), staged_lds, stream, b.records, b.group_cursor,
+                         dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor,
                          b.digits, b.tasks);
     } else {
       hipLaunchKernelGGL(k_group_scatter<false>, dim3(plan.max_task_slices, num_tasks),
-                         dim3(kSortThreads), part_lds, stream, b.records, b.group_cursor, b.digits,
+                         dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
     hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads),
-                       0, stream, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                       0, fs, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
                        b.group_chunk, b.tasks);
     // oversized groups (skewed digits); both launches find nothing to do on uniform data
-    hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, stream,
+    hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
                        b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,
                        b.big_tasks);
-    hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, stream,
+    hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
                        b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
                        b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
   });
-  if (join_prepare) BZ_HIP_CHECK(hipStreamWaitEvent(stream, ctx.join, 0));
-  ctx.timer.timed(timing, 3, stream, [&] {
+  if (mode.split) ctx.front_done[k & 3].record(fs);
+
+  // ---- accumulate: rewrites the bucket sums / head partials the reduce two batches ago read
+  if (mode.split) ctx.front_done[k & 3].wait(as);
+  wait_for(earlier(ctx.reduce_done, 2), as);
+  ctx.timer.timed(timing, 3, as, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
-                       stream, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
+                       as, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
                        b.addends, b.tasks);
   });
-  // bucket reduction, then whole columns in one k_horner launch (the range covers every window,
-  // first and last): on the caller's stream, or forked onto the tail stream (msm_context::tail)
-  hipStream_t tail_stream = stream;
-  auto fork = [&] {
-    if (!tail_on_side) return;
-    tail_stream = ctx.tail_stream();
-    BZ_HIP_CHECK(hipEventRecord(ctx.tail_fork, stream));
-    BZ_HIP_CHECK(hipStreamWaitEvent(tail_stream, ctx.tail_fork, 0));
-  };
-  if (ctx.tail_includes_reduce) fork();
-  ctx.timer.timed(timing, 4, tail_stream, [&] {
+  if (mode.piped) ctx.acc_done[k & 3].record(as);
+
+  // ---- reduce: rewrites the partials / entry counts the horner two batches ago read
+  if (mode.piped) ctx.acc_done[k & 3].wait(rs);
+  wait_for(earlier(ctx.horner_done, 2), rs);
+  ctx.timer.timed(timing, 4, rs, [&] {
     hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
-                       tail_stream, b.partials, b.partial_stride, b.task_total, b.bucket_sums,
-                       b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
+                       rs, b.partials, b.partial_stride, b.task_total, b.bucket_sums, b.heads,
+                       b.bucket_end, b.tasks, plan.reduce_segment_log2);
   });
-  if (!ctx.tail_includes_reduce) fork();
-  if (tail_on_side && ctx.tail_includes_reduce && ctx.two_tail_streams) {
-    // k_horner on the second tail stream: beside the next call's k_reduce on the first
-    BZ_HIP_CHECK(hipEventRecord(ctx.tail_mid, tail_stream));
-    tail_stream = ctx.tail2;
-    BZ_HIP_CHECK(hipStreamWaitEvent(tail_stream, ctx.tail_mid, 0));
-  }
-  ctx.timer.timed(timing, 5, tail_stream, [&] {
-    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, tail_stream, d_out,
+  if (mode.piped) ctx.reduce_done[k & 3].record(rs);
+
+  // ---- horner: whole columns in one launch (the range covers every window, first and last)
+  if (mode.piped) ctx.reduce_done[k & 3].wait(hs);
+  ctx.timer.timed(timing, 5, hs, [&] {
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
                        b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
                        plan.reduce_segment_log2);
   });
-  if (tail_on_side) {
-    BZ_HIP_CHECK(hipEventRecord(ctx.tail_done[parity], tail_stream));
-    ctx.tail_pending[parity] = true;
-    ctx.tail_layout = layout;
-    ctx.tail_parity = parity ^ 1;
-    // the tail before this one has had this batch's front and accumulation to finish beside: the
-    // caller's stream picks it up here (so a deferred call's result is complete on the stream
-    // once the next call has been enqueued)
-    ctx.join_tail(stream, parity ^ 1);
+  if (mode.piped) {
+    ctx.horner_done[k & 3].record(hs);
+    ctx.pipe_layout = layout;
+    ctx.seq = k + 1;
+    // The caller's stream picks up the batch TWO before this one (whose buffers this batch reused,
+    // so it is long done): a pipelined call's result is complete on the stream once two further
+    // calls have been enqueued, or after a flush.  (Waiting for the previous batch here would put
+    // its horner in front of the next call's entry mark, i.e. of the next front: the front of
+    // batch k + 1 could not start until the tails of batch k - 1 are through, most of the way into
+    // accumulation k, which is what it is meant to run beside.)
+    if (k >= 2 && (ctx.joined < k - 1 || stream != ctx.joined_on)) {
+      ctx.horner_done[(k - 2) & 3].wait(stream);
+      ctx.joined = k - 1;
+      ctx.joined_on = stream;
+    }
   }
   if (timing) ctx.timer.calls += 1;
   g_kernel_launches += 10;

@@ -81,20 +81,25 @@ void bzamd_stage_timing_begin(uint64_t max_calls);
 void bzamd_stage_timing_begin_masked(uint64_t max_calls, uint32_t stage_mask);
 uint64_t bzamd_stage_timing_collect(double* out_ms);
 
-/* Throughput mode for a sequence of device-resident MSM calls.  The last two stages of a call with
- * few columns are latency chains that leave the machine nearly idle -- the bucket reduction runs one
- * wavefront per SIMD, the final stage ONE workgroup per column (~250 dependent doublings and the
- * encoding's 250 squarings): 0.39 of a 1.24 ms call at 2^20 curve25519 rows.
+/* Throughput mode for a sequence of device-resident MSM calls.  A call with few columns is four
+ * stages with complementary bottlenecks: a front of short HBM-bound kernels (generator conversion,
+ * recoding, bucket sort), the integer-issue-bound bucket accumulation, and two latency chains that
+ * leave the machine nearly idle -- the bucket reduction at one wavefront per SIMD and the final
+ * stage at ONE workgroup per column (~250 dependent doublings, the encoding's 250 squarings).
  * bzamd_pipeline_next() makes the NEXT MSM enqueued through a device entry point of this header
- * (bzamd_msm_device*, bzamd_fixed_packed_multiexponentiation_device) on the current device run
- * those stages on an internal stream, beside the generator conversion, recoding, sorting and
- * accumulation of the call that follows (which must have the same shape to overlap: the engine
- * otherwise simply waits); the caller's stream does not wait for them.  The commitments of such a
- * call are complete on `stream` only once a later such call on the device has been enqueued on
- * it, or after bzamd_pipeline_flush(stream): do not read them earlier.  Calls with 64 or more
- * columns ignore the request (their tails fill the machine).  A pipelined sequence lives on ONE
- * stream (the join is enqueued on the stream of the later call, or of the flush) and one caller
- * thread per device.  (Measured on MI355X, 2^20 rows: ~1.0 instead of 1.24 ms per call.) */
+ * (bzamd_msm_device*, bzamd_fixed_packed_multiexponentiation_device) on the current device run its
+ * stages on internal streams of the engine, where the front of call k + 1 runs beside the
+ * accumulation of call k and the tails of call k - 1 (the calls must have the same shape to
+ * overlap: the engine otherwise simply waits).  The caller's `stream` only orders the call: its
+ * front starts behind whatever the stream holds when the call is made (the operands are ready),
+ * and the stream waits for that front (the operands may be overwritten in stream order right after
+ * the call returns).  The commitments of such a call are complete on `stream` only once TWO later
+ * such calls on the device have been enqueued on it, or after bzamd_pipeline_flush(stream): do not
+ * read them earlier.  Calls with 64 or more columns ignore the request (their tails fill the
+ * machine).  A pipelined sequence lives on ONE stream and one caller thread per device.  Pass a
+ * stream of your own (hipStreamNonBlocking): every operation on the NULL stream implicitly waits for
+ * the engine's internal streams and serialises the stages again (still correct, no overlap).
+ * (Measured on MI355X, 2^20 curve25519 rows: see DESIGN.md section 9.) */
 void bzamd_pipeline_next(void);
 void bzamd_pipeline_flush(void* stream);
 

@@ -54,37 +54,52 @@ def main():
             vals = [f"{sum(counters[k][c]) / len(counters[k][c]):.4g}" if c in counters[k] else ""
                     for c in names]
             print(f"| {k} | " + " | ".join(meta[k]) + " | " + " | ".join(vals) + " |")
-        acc = [k for k in counters if k.startswith("k_accumulate")]
-        if acc and "FETCH_SIZE" in counters[acc[0]] and "WRITE_SIZE" in counters[acc[0]]:
-            import json
-            f = sum(counters[acc[0]]["FETCH_SIZE"]) / len(counters[acc[0]]["FETCH_SIZE"])
-            w = sum(counters[acc[0]]["WRITE_SIZE"]) / len(counters[acc[0]]["WRITE_SIZE"])
-            c = counters[acc[0]]
-            valu_busy = None
-            if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        def avg(k, c):
+            v = counters[k].get(c)
+            return sum(v) / len(v) if v else None
+
+        def kernel_entry(k):
+            f, w = avg(k, "FETCH_SIZE"), avg(k, "WRITE_SIZE")
+            e = {"fetch_kib": f, "write_kib": w, "launches_averaged": len(counters[k].get("FETCH_SIZE", []))}
+            if f is not None and w is not None:
+                e["bytes_per_launch"] = (2 * f + w) * 1024
+                e["raw_bytes_per_launch"] = (f + w) * 1024
+            act, cyc = avg(k, "SQ_ACTIVE_INST_VALU"), avg(k, "GRBM_GUI_ACTIVE")
+            if act is not None and cyc:
                 # quad-cycles of VALU issue summed over 1024 SIMDs / (cycles per XCD x SIMDs);
                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                act = sum(c["SQ_ACTIVE_INST_VALU"]) / len(c["SQ_ACTIVE_INST_VALU"])
-                cyc = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8
-                valu_busy = 4 * act / (1024 * cyc)
+                e["valu_busy"] = 4 * act / (1024 * cyc / 8)
+            for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY",
+                      "SQ_WAIT_ANY", "SQ_INST_CYCLES_VMEM", "GRBM_GUI_ACTIVE"):
+                if avg(k, c) is not None:
+                    e[c.lower() + "_per_launch"] = avg(k, c)
+            return e
+
+        acc = sorted(k for k in counters if k.startswith("k_accumulate"))
+        head = [k for k in acc if k == "k_accumulate<bz::ed25519_msm>"] or acc
+        if head and "FETCH_SIZE" in counters[head[0]] and "WRITE_SIZE" in counters[head[0]]:
+            import json
+            h = kernel_entry(head[0])
             # gfx950 correction of the guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies a
             # 128-byte request of 16-byte-per-lane loads as 64 bytes -> x 2.  Calibrated in the
             # same run on a kernel with known bytes: k_prepare_addends reads n x 160 B and writes
             # n x 128 B (n = 2^20: 167.8 MB / 134.2 MB).
             cal = {}
-            prep = [k for k in counters if k.startswith("k_prepare_addends<")]
+            prep = [k for k in counters if k.startswith("k_prepare_addends_staged<bz::ed25519_msm")]
             if prep and "FETCH_SIZE" in counters[prep[0]]:
-                pf = sum(counters[prep[0]]["FETCH_SIZE"]) / len(counters[prep[0]]["FETCH_SIZE"])
-                pw = sum(counters[prep[0]]["WRITE_SIZE"]) / len(counters[prep[0]]["WRITE_SIZE"])
+                pf, pw = avg(prep[0], "FETCH_SIZE"), avg(prep[0], "WRITE_SIZE")
                 cal = {"kernel": prep[0], "known_read_bytes": (1 << 20) * 160,
                        "fetch_size_bytes_raw": pf * 1024, "known_write_bytes": (1 << 20) * 128,
                        "write_size_bytes_raw": pw * 1024,
                        "read_factor": (1 << 20) * 160 / (pf * 1024),
                        "write_factor": (1 << 20) * 128 / (pw * 1024)}
-            out = {"kernel": acc[0], "fetch_kib": f, "write_kib": w, "valu_busy": valu_busy,
-                   "k_accumulate_bytes_per_launch": (2 * f + w) * 1024,
-                   "raw_bytes_per_launch": (f + w) * 1024,
+            out = {"kernel": head[0], "fetch_kib": h["fetch_kib"], "write_kib": h["write_kib"],
+                   "valu_busy": h.get("valu_busy"),
+                   "k_accumulate_bytes_per_launch": h["bytes_per_launch"],
+                   "raw_bytes_per_launch": h["raw_bytes_per_launch"],
                    "calibration": cal,
+                   # every k_accumulate instantiation of the run (bench.py's configs read theirs)
+                   "kernels": {k: kernel_entry(k) for k in acc},
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                              "tools/prof/run_pmc.sh) of `python bench.py` on MI355X, summarised "
                              "by profiles/summarize_pmc.py from " + root,

@@ -394,17 +394,28 @@ def test_device_resident_entry_points(gpu_backend, oracle):
             lib.bzamd_generators_free(h)
 
 
-def test_pipelined_calls(gpu_backend, oracle):
+@pytest.mark.parametrize("side_stream", [True, False])
+def test_pipelined_calls(gpu_backend, oracle, side_stream):
     """bzamd_pipeline_next / bzamd_pipeline_flush (include/blitzar_amd.h): a sequence of calls whose
-    last stage runs on the engine's tail stream beside the front of the next call.  Calls with the
-    same descriptors (the fast path: nothing is re-uploaded), with different ones (the engine joins
-    before it overwrites what the pending stage reads), on two curves and through the resident
-    entry point; every output buffer is read after the NEXT call was enqueued or after a flush."""
+    stages overlap on the engine's own streams (front of call k + 1 beside the accumulation of call k
+    beside the tails of call k - 1).  Calls with the same descriptors (the fast path: nothing is
+    re-uploaded), with different ones, on two curves and through the resident entry point; every
+    output buffer is read after TWO further calls were enqueued or after a flush, on the caller's
+    stream; operands are overwritten right behind a call (they are consumed in stream order).  On
+    a stream of the caller's own (no implicit synchronisation hides an ordering bug) and on the
+    NULL stream."""
     import ctypes
     import torch
     api = gpu_backend
     lib = api.load()
     dev = torch.device("cuda", 0)
+    torch_stream = torch.cuda.Stream(device=dev) if side_stream else torch.cuda.current_stream()
+    with torch.cuda.stream(torch_stream):
+        _pipelined_calls(api, lib, oracle, dev, ctypes, torch)
+    torch.cuda.synchronize()
+
+
+def _pipelined_calls(api, lib, oracle, dev, ctypes, torch):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(33)
     jobs = []
@@ -419,6 +430,7 @@ def test_pipelined_calls(gpu_backend, oracle):
             desc = (api.sxt_sequence_descriptor * 1)()
             desc[0] = api.sxt_sequence_descriptor(nbytes, rows, d_col.data_ptr(), 0)
             jobs.append((curve_id, d_gens, d_col, desc, want))
+    torch.cuda.current_stream().synchronize()
     # every job three times in a row (identical descriptors), jobs interleaved (changing ones),
     # and two jobs of one shape over different buffers alternating (the overlapping path with a
     # descriptor upload per call)
@@ -431,15 +443,39 @@ def test_pipelined_calls(gpu_backend, oracle):
         lib.bzamd_pipeline_next()
         lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, desc,
                              ctypes.c_void_p(d_gens.data_ptr()), stream)
-        if outs:  # the previous call is complete on the stream now: copy it out, stream-ordered
-            copies.append((outs[-1][0], outs[-1][1].clone()))
         outs.append((j, out))
+        if len(outs) >= 3:  # two calls later a result is complete on the stream: copy it out
+            copies.append((outs[-3][0], outs[-3][1].clone()))
     lib.bzamd_pipeline_flush(stream)
-    copies.append((outs[-1][0], outs[-1][1].clone()))
+    for j, out in outs[-2:]:
+        copies.append((j, out.clone()))
     torch.cuda.synchronize()
     assert len(copies) == len(order)
     for j, got in copies:
         assert np.array_equal(got.cpu().numpy(), jobs[j][4]), f"pipelined job {j}"
+    # operands are consumed in stream order: a scratch column and scratch generators refilled right
+    # behind every call, alternating between two jobs of one shape
+    curve_id = jobs[0][0]
+    scratch_col = torch.empty_like(jobs[0][2])
+    scratch_gens = torch.empty_like(jobs[0][1])
+    sdesc = (api.sxt_sequence_descriptor * 1)()
+    sdesc[0] = api.sxt_sequence_descriptor(32, 40000, scratch_col.data_ptr(), 0)
+    results = []
+    for i in range(12):
+        j = 0 if i % 2 == 0 else 3
+        scratch_col.copy_(jobs[j][2])
+        scratch_gens.copy_(jobs[j][1])
+        out = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+        lib.bzamd_pipeline_next()
+        lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, sdesc,
+                             ctypes.c_void_p(scratch_gens.data_ptr()), stream)
+        scratch_col.zero_()   # behind the call in stream order: must not reach its front
+        scratch_gens.zero_()
+        results.append((j, out))
+    lib.bzamd_pipeline_flush(stream)
+    torch.cuda.synchronize()
+    for j, out in results:
+        assert np.array_equal(out.cpu().numpy(), jobs[j][4]), "operands overwritten behind a call"
     # a plain call after a pipelined one needs no flush of its own
     curve_id, d_gens, _, desc, want = jobs[0]
     h = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(d_gens.data_ptr()), 40000, stream)
@@ -463,14 +499,15 @@ def test_pipelined_calls(gpu_backend, oracle):
         oracle.commit(0, host_cols, host_gens))
     lib.bzamd_pipeline_flush(stream)
     # a random mix: deferred and plain calls, one and five columns, flushes now and then; a
-    # deferred result is read once something was enqueued after its call
+    # deferred result is read once two further calls, a plain call or a flush were enqueued
     curve_id, d_gens = jobs[0][0], jobs[0][1]
     five = (api.sxt_sequence_descriptor * 5)()
     for c in range(5):
         five[c] = jobs[c % 4][3][0]
     want5 = np.concatenate([jobs[c % 4][4] for c in range(5)])
-    pending = []
-    for _ in range(40):
+    pending = []  # [want, out, calls enqueued since]
+    mixed = []
+    for _ in range(60):
         kind = int(rng.integers(0, 4))
         if kind == 3:
             out = torch.zeros((5, 32), dtype=torch.uint8, device=dev)
@@ -489,21 +526,26 @@ def test_pipelined_calls(gpu_backend, oracle):
             lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, jobs[j][3],
                                  ctypes.c_void_p(d_gens.data_ptr()), stream)
             want_k = jobs[j][4]
-        for w, o in pending:  # complete on the stream by now
-            copies.append((w, o.clone()))
-        pending = [(want_k, out)] if deferred else []
-        if not deferred:
-            copies.append((want_k, out.clone()))
+        for item in pending:
+            item[2] += 1
+        done = [it for it in pending if it[2] >= 2 or not deferred]
+        pending = [it for it in pending if not (it[2] >= 2 or not deferred)]
+        for w, o, _ in done:  # complete on the stream by now
+            mixed.append((w, o.clone()))
+        if deferred:
+            pending.append([want_k, out, 0])
+        else:
+            mixed.append((want_k, out.clone()))
         if rng.integers(0, 5) == 0:
             lib.bzamd_pipeline_flush(stream)
-            for w, o in pending:
-                copies.append((w, o.clone()))
+            for w, o, _ in pending:
+                mixed.append((w, o.clone()))
             pending = []
     lib.bzamd_pipeline_flush(stream)
-    for w, o in pending:
-        copies.append((w, o.clone()))
+    for w, o, _ in pending:
+        mixed.append((w, o.clone()))
     torch.cuda.synchronize()
-    for w, got in copies[len(order):]:
+    for w, got in mixed:
         assert np.array_equal(got.cpu().numpy(), w)
 
 
