@@ -55,9 +55,29 @@ struct resident_table {
     if (const char* v = std::getenv("BLITZAR_AMD_WINDOW_TABLE_MIN")) {
       least = std::strtoull(v, nullptr, 10); // tests: tables for small sets too
     }
-    const u32 windows = wanted && count >= least ? kWindowTableSlices : 1;
+    u32 windows = wanted && count >= least ? kWindowTableSlices : 1;
     const u64 stride = (count + 7) & ~u64{7};
-    BZ_HIP_CHECK(hipMalloc(&d_addends, vt.resident_addend_size * (stride * windows + 1)));
+    const size_t row = vt.resident_addend_size;
+    if (windows > 1) {
+      // 17 x the memory of the plain addends, on every device the backend drives: only while it is
+      // a modest share of what the device has left (a quarter of the free HBM, or
+      // BLITZAR_AMD_WINDOW_TABLE_MAX_BYTES) -- a caller who precomputes 2^24 generators and commits
+      // short columns would otherwise pay 36 GB per device for tables no call of his uses
+      size_t free_bytes = 0, total_bytes = 0;
+      BZ_HIP_CHECK(hipMemGetInfo(&free_bytes, &total_bytes));
+      size_t cap = free_bytes / 4;
+      if (const char* v = std::getenv("BLITZAR_AMD_WINDOW_TABLE_MAX_BYTES")) {
+        cap = static_cast<size_t>(std::strtoull(v, nullptr, 10));
+      }
+      if (row * stride * windows > cap) windows = 1;
+    }
+    hipError_t err = hipMalloc(&d_addends, row * (stride * windows + 1));
+    if (err != hipSuccess && windows > 1) {
+      (void)hipGetLastError(); // no room for the table after all: plain addends
+      windows = 1;
+      err = hipMalloc(&d_addends, row * (stride + 1));
+    }
+    BZ_HIP_CHECK(err);
     vt.build_window_table(d_addends, d_source, source_projective, count, stride, windows, stream);
     if (windows > 1) {
       shape.stride = stride;

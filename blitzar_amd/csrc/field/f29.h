@@ -115,21 +115,15 @@ BZ_HD fe29 weak_reduce(const fe29& f) {
   return h;
 }
 
-// High columns 9..16 and the fold 2^261 = 1216 (mod p).  BZ_F29_FOLD selects how the high columns
-// reach the low ones:
-//   0: one accumulator rides through columns 9..16, each carried into a 29-bit limb u[k] (mask +
-//      64-bit shift per column) that enters low column k as 1216 u[k]: 81 + 10 mads;
-//   1: every high column keeps its own 64-bit sum c = lo + 2^32 hi and is folded as it stands,
-//      1216 lo into low column k and 8 * 1216 hi into low column k + 1 (2^32 = 8 * 2^29): 81 + 17
-//      mads, but no mask / shift on the high columns.  A low column receives at most
-//      9 * 6 * 2^58 (products, B(f) B(g) <= 6) + 2^43 + 2^46 + 2^35 (carry) < 2^64.
-#ifndef BZ_F29_FOLD
-#define BZ_F29_FOLD 1
-#endif
+// High columns 9..16 and the fold 2^261 = 1216 (mod p): every high column keeps its own 64-bit sum
+// c = lo + 2^32 hi and is folded as it stands, 1216 lo into low column k and 8 * 1216 hi into low
+// column k + 1 (2^32 = 8 * 2^29): 81 + 17 mads, no mask / shift on the high columns.  A low column
+// receives at most 9 * 6 * 2^58 (products, B(f) B(g) <= 6) + 2^43 + 2^46 + 2^35 (carry) < 2^64.
+// (Carrying the high columns into 29-bit limbs first -- 81 + 10 mads but a mask and a 64-bit shift
+// per column -- measured 3 % slower at config 2, profiles/round2_ab_f29_fold_waves.log.)
 BZ_HD fe29 mul(const fe29& f, const fe29& g) {
   fe29 h;
   u64 acc = 0;
-#if BZ_F29_FOLD == 1
   u64 c[8];
 #pragma unroll
   for (int k = 9; k <= 16; ++k) {
@@ -147,28 +141,6 @@ BZ_HD fe29 mul(const fe29& f, const fe29& g) {
     h.v[k] = static_cast<u32>(acc) & kMask;
     acc >>= 29;
   }
-#else
-  // columns 9..16, carried into 29-bit limbs u[0..7] and a top carry u[8] (< 2^32 for
-  // B(f) B(g) <= 6): these fold onto columns 0..8 with the factor 1216
-  u32 u[9];
-#pragma unroll
-  for (int k = 9; k <= 16; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc = mad(f.v[i], g.v[k - i], acc);
-    u[k - 9] = static_cast<u32>(acc) & kMask;
-    acc >>= 29;
-  }
-  u[8] = static_cast<u32>(acc);
-  acc = 0;
-#pragma unroll
-  for (int k = 0; k <= 8; ++k) {
-    acc = mad(u[k], kWrap, acc);
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc = mad(f.v[i], g.v[k - i], acc);
-    h.v[k] = static_cast<u32>(acc) & kMask;
-    acc >>= 29;
-  }
-#endif
   // acc < 2^35 sits at 2^261: fold once more, then one carry step
   const u64 t0 = mad(static_cast<u32>(acc), kWrap, h.v[0]) +
                  (static_cast<u64>(static_cast<u32>(acc >> 32) * kWrap) << 32);
@@ -183,7 +155,6 @@ BZ_HD fe29 sq(const fe29& f) {
   for (int i = 0; i < 9; ++i) d[i] = 2 * f.v[i];
   fe29 h;
   u64 acc = 0;
-#if BZ_F29_FOLD == 1
   u64 c[8];
 #pragma unroll
   for (int k = 9; k <= 16; ++k) {
@@ -203,28 +174,6 @@ BZ_HD fe29 sq(const fe29& f) {
     h.v[k] = static_cast<u32>(acc) & kMask;
     acc >>= 29;
   }
-#else
-  u32 u[9];
-#pragma unroll
-  for (int k = 9; k <= 16; ++k) {
-#pragma unroll
-    for (int i = k - 8; 2 * i < k; ++i) acc = mad(d[i], f.v[k - i], acc);
-    if (k % 2 == 0) acc = mad(f.v[k / 2], f.v[k / 2], acc);
-    u[k - 9] = static_cast<u32>(acc) & kMask;
-    acc >>= 29;
-  }
-  u[8] = static_cast<u32>(acc);
-  acc = 0;
-#pragma unroll
-  for (int k = 0; k <= 8; ++k) {
-    acc = mad(u[k], kWrap, acc);
-#pragma unroll
-    for (int i = 0; 2 * i < k; ++i) acc = mad(d[i], f.v[k - i], acc);
-    if (k % 2 == 0) acc = mad(f.v[k / 2], f.v[k / 2], acc);
-    h.v[k] = static_cast<u32>(acc) & kMask;
-    acc >>= 29;
-  }
-#endif
   const u64 t0 = mad(static_cast<u32>(acc), kWrap, h.v[0]) +
                  (static_cast<u64>(static_cast<u32>(acc >> 32) * kWrap) << 32);
   h.v[0] = static_cast<u32>(t0) & kMask;

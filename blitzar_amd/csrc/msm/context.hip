@@ -66,6 +66,11 @@ msm_context* msm_context_new() {
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");
     ctx->two_tail_streams = streams == 2;
   }
+  if (const char* v = std::getenv("BLITZAR_AMD_FRONT_WAVES")) {
+    const unsigned long waves = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(waves <= 8, "BLITZAR_AMD_FRONT_WAVES must be in [0, 8]");
+    ctx->front_waves = static_cast<u32>(waves);
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_FRONT_CUS")) {
     const unsigned long cus = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(cus <= 128, "BLITZAR_AMD_FRONT_CUS must be in [0, 128]");

@@ -74,10 +74,7 @@ struct ed25519_msm {
   // k_accumulate's gather: the row's first two 32-byte pieces (Y+X | Y-X) arrive exchanged when
   // the digit is negative -- by address, two 16-byte loads each -- so the addition needs no selects
   // on them (18 v_cndmask per addition) and only conditions 2dT (`accumulate_gathered`)
-#ifndef BZ_SIGNED_GATHER
-#define BZ_SIGNED_GATHER 1
-#endif
-  static constexpr bool has_signed_gather = BZ_SIGNED_GATHER != 0;
+  static constexpr bool has_signed_gather = true;
   BZ_HD static addend gather(const addend* table, u32 row, bool negate) {
     return ed29::gather_signed(table, row, negate);
   }

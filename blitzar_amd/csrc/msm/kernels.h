@@ -993,9 +993,6 @@ template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 d
   return r;
 }
 
-#ifndef BZ_ACC_PIPELINE
-#define BZ_ACC_PIPELINE 2
-#endif
 // wave priorities (s_setprio, 0..3) of the two tail kernels, see k_reduce
 #ifndef BZ_REDUCE_PRIO
 #define BZ_REDUCE_PRIO 3
@@ -1026,7 +1023,6 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   const u32* idx = sorted + task.entry_base;
   typename C::point* sums = bucket_sums + task.bucket_base;
   typename C::point acc = C::identity();
-#if BZ_ACC_PIPELINE == 2
   // Software pipeline, one entry ahead, with no register copies: at the top of an iteration the
   // staged row (the packed words the previous iteration's gather delivered) is turned into the
   // operand the addition consumes -- pinned there, so the staging registers are dead before the
@@ -1084,36 +1080,6 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
       C::accumulate(acc, q, negate);
     }
   }
-#else
-  // software pipeline, one entry ahead: the gather of the next addend (two dependent loads:
-  // index, then 144..192 bytes from a random row of the generator table) is in flight while the
-  // current addition (~1500 VALU instructions) executes, so a wave hides its own memory latency
-  // instead of relying on the 3-4 co-resident waves all being out of phase.
-  u32 e_next = idx[lo];
-  u32 e_after = lo + 1 < hi ? idx[lo + 1] : 0;
-  typename C::addend q_next = addends[e_next & 0x7fffffffu];
-  for (u32 i = lo; i < hi; ++i) {
-    if (i == b_end) {
-      if (owned) {
-        sums[b] = acc;
-      } else {
-        heads[task.segment_base + seg] = acc;
-      }
-      do {
-        ++b;
-        b_end = ends[b];
-      } while (b_end == i);
-      owned = true;
-      acc = C::identity();
-    }
-    const u32 e = e_next;
-    const typename C::addend q = q_next;
-    e_next = e_after; // index loaded one iteration ago: the addend gather below does not wait on it
-    if (i + 1 < hi) q_next = addends[e_next & 0x7fffffffu];
-    if (i + 2 < hi) e_after = idx[i + 2];
-    C::accumulate(acc, q, (e >> 31) != 0);
-  }
-#endif
   // runs of `whole` lanes (necessarily of one bucket) -> one head per run and wavefront
   const unsigned long long whole_mask = __ballot(whole);
   const u32 lane = threadIdx.x & 63;
@@ -1126,15 +1092,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
     }
     if (whole && lane != 0 && ((whole_mask >> (lane - 1)) & 1) != 0) write_head = false;
   }
-#if BZ_ACC_PIPELINE == 2
   if (owned || write_head) *flush_to = acc;
-#else
-  if (owned) {
-    sums[b] = acc;
-  } else if (write_head) {
-    heads[task.segment_base + seg] = acc;
-  }
-#endif
 }
 
 // complete sum of bucket b of a task: the owner's partial plus the heads of the following

@@ -80,7 +80,7 @@ ed_point scalar_multiply(const ed_point& p, const u8 k[32]) {
 // high ones count as zero (fold.cc:30-45).  m_* in Montgomery form, x plain: the products are plain.
 // In place (out == x) is safe: entry i is only read by its own lane, entries >= mid are not written.
 __global__ void __launch_bounds__(256)
-    k_fold_scalars(u64* __restrict__ out, const u64* x, s25::fe m_low, s25::fe m_high, u32 mid,
+    k_fold_scalars(u64* out, const u64* x, s25::fe m_low, s25::fe m_high, u32 mid,
                    u32 len) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= mid) return;
