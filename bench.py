@@ -453,6 +453,28 @@ def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll):
             "verified": "every rank's commitments bit-exact vs the reference's curve code"}
 
 
+def in_process_multi_device():
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "pipeline_bench", "_build", "multi_device_check")
+    if not os.path.exists(exe):
+        return {"error": "tools/pipeline_bench/_build/multi_device_check is not built"}
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("BLITZAR_AMD_NUM_DEVICES", "BLITZAR_AMD_FORCE_SHARDS")}
+    try:
+        r = subprocess.run([exe, "--log2n", "18", "--columns", "16", "--steps", "3"], env=env,
+                           capture_output=True, text=True, timeout=240)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-600:]}
+        out = json.loads(lines[-1])
+        out["rc"] = r.returncode
+        out["what"] = ("tools/pipeline_bench/multi_device_check.cc: one process, every visible "
+                       "device; results compared with the same work on device 0 alone")
+        return out
+    except Exception as exc:  # a hang or crash there must not cost the bench line
+        return {"error": repr(exc)[:300]}
+
+
 #--------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -546,9 +568,31 @@ def main():
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
+    dist_info = None
     if world > 1:
-        mine = gathered.cpu().numpy().reshape(world, max_steps, 32)[rank, :args.steps]
-        assert np.array_equal(mine, all_outputs), "all-gather returned something else"
+        everyone = gathered.cpu().numpy().reshape(world, max_steps, 32)[:, :args.steps]
+        assert np.array_equal(everyone[rank], all_outputs), "all-gather returned something else"
+        # what the collective really spanned: every rank commits a DIFFERENT column (mt19937{rank}),
+        # so the gathered buffer holds one distinct commitment per participating rank
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(),
+              "device_name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+              "commitment": bytes(timed_output[0]).hex()}
+        peers = [None] * world
+        dist.all_gather_object(peers, me)
+        dist_info = {
+            "backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""),
+            "rccl_world_size": dist.get_world_size(),
+            "ranks": peers,
+            "all_gather_bytes": int(gathered.numel()),
+            "all_gather_check": "every rank found its own K commitments in the gathered buffer; "
+                                f"{len({bytes(everyone[r, -1]).hex() for r in range(world)})} "
+                                f"distinct commitments from {world} ranks",
+            "distinct_commitments_gathered": len({bytes(everyone[r, -1]).hex()
+                                                  for r in range(world)}),
+            "distinct_devices": len({(p["device_index"], p["pci_bus_id"]) for p in peers}),
+        }
+        assert args.dry_run_one_gpu or dist_info["distinct_commitments_gathered"] == world
     # untimed passes: the six stage times, and the latency of a lone call (no throughput mode)
     stage_steps = min(args.steps, 50)
     clock = StageClock(lib, stage_steps)
@@ -679,14 +723,25 @@ def main():
             result["configs"] = run_configs(lib, oracle, args, dev, stream)
         if sharded is not None:
             result["configs"] = [sharded]
-        print(json.dumps(result), flush=True)
-    elif world == 1:
-        pass
+            # the informative multi-GPU number: a FIXED job (config 4's 256 columns) cut over the ranks
+            result["strong_scaling"] = {k: sharded[k] for k in
+                                        ("config", "columns_per_gpu", "ms_per_call",
+                                         "scalar_point_ops_per_s", "commitments_per_s", "verified")}
+        if dist_info is not None:
+            result["distributed"] = dist_info
 
     api.reset_for_testing()
     if world > 1:
         coll.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # one PROCESS driving every visible device through the C ABI (bzamd_msm_multi_device: RCCL
+        # all-gather inside the library; the sharded blocking sxt_* entry points), checked against
+        # the same work on device 0 alone -- in a child process with a timeout, after this process
+        # has released its GPU and the process group: a failure there cannot touch the line above
+        if not args.no_configs and not args.dry_run_one_gpu:
+            result["in_process_multi_device"] = in_process_multi_device()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -137,6 +137,19 @@ def load():
     lib.bzamd_transcript_init.argtypes = [vp, ctypes.c_char_p, u64]
     lib.bzamd_transcript_init.restype = None
     lib.bzamd_num_devices.restype = ctypes.c_int
+    lib.bzamd_set_window_bits.argtypes = [u32]
+    lib.bzamd_set_window_bits.restype = None
+    lib.bzamd_set_max_rows_per_pass.argtypes = [u64]
+    lib.bzamd_set_max_rows_per_pass.restype = None
+    lib.bzamd_device_id.argtypes = [ctypes.c_int]
+    lib.bzamd_device_id.restype = ctypes.c_int
+    lib.bzamd_multi_device_columns_per_device.argtypes = [u32]
+    lib.bzamd_multi_device_columns_per_device.restype = u32
+    lib.bzamd_multi_device_exchange.restype = ctypes.c_char_p
+    lib.bzamd_msm_multi_device.argtypes = [cu, ctypes.POINTER(vp), u32,
+                                           ctypes.POINTER(sxt_sequence_descriptor),
+                                           ctypes.POINTER(vp)]
+    lib.bzamd_msm_multi_device.restype = None
     lib.bzamd_set_shard_min_bytes.argtypes = [u64]
     lib.bzamd_set_shard_min_bytes.restype = None
     lib.bzamd_accumulate_form.restype = ctypes.c_int

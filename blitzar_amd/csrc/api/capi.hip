@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "blitzar_amd/csrc/api/rccl_loader.h"
 #include "blitzar_amd/csrc/api/state.h"
 #include "blitzar_amd/csrc/fixed/dump.h"
 #include "blitzar_amd/csrc/fixed/handle.h"
@@ -113,9 +114,10 @@ struct checked_columns {
 };
 
 // reference: populate_exponent_sequence, cbindings/pedersen.cc:44-68 (+ the signed-width rule of
-// sxt/multiexp/pippenger/exponent_aggregates_computation.cc:99-101).  One documented narrowing:
-// the engine indexes rows with 31 bits (32-bit sorted entries = row | sign << 31), so a sequence
-// is limited to 2^31 - 1 rows (69 GB of 32-byte scalars; INTEGRATION.md "Limits").
+// sxt/multiexp/pippenger/exponent_aggregates_computation.cc:99-101).  The engine indexes the rows of
+// a pass with 31 bits (32-bit sorted entries = row | sign << 31); sequences of any u64 length
+// (sxt/multiexp/base/exponent_sequence.h:25-42) are cut into passes of at most
+// g_max_rows_per_pass rows whose projective partial results are folded (exact group addition).
 checked_columns check_descriptors(const sxt_sequence_descriptor* descriptors, u32 num_sequences) {
   BZ_RELEASE_ASSERT(descriptors != nullptr, "descriptors is null");
   checked_columns r;
@@ -127,7 +129,6 @@ checked_columns check_descriptors(const sxt_sequence_descriptor* descriptors, u3
                       "element_nbytes must be in [1, 32]");
     BZ_RELEASE_ASSERT(!d.is_signed || d.element_nbytes <= 16,
                       "signed sequences need element_nbytes <= 16");
-    BZ_RELEASE_ASSERT(d.n < (uint64_t{1} << 31), "sequences are limited to 2^31 - 1 rows");
     r.cols[i] = byte_column(d.data, d.n, d.element_nbytes, d.is_signed != 0);
     r.longest = std::max<u64>(r.longest, d.n);
     r.total_bytes += device_arena::padded(static_cast<size_t>(d.n) * d.element_nbytes + 32);
@@ -208,6 +209,10 @@ template <class F> void run_on_devices(size_t count, F&& fn) {
 // bytes of scalars below which a call stays on one device (threads + extra synchronisations cost
 // ~0.1 ms); tests lower it to force the sharded paths on small inputs
 std::atomic<u64> g_shard_min_bytes{u64{1} << 20};
+
+// rows of a sequence one pass of the engine takes (2^28: 77 GB of generators + addends per pass on
+// curve25519); longer sequences run in several passes.  Tests lower it to force the multi-pass path.
+std::atomic<u64> g_max_rows_per_pass{u64{1} << 28};
 
 // Enqueue the commitment of `cols` (HOST column pointers) on one device: stage operands into the
 // device's io arena, run the engine, leave the results in the arena.  Returns the device pointer of
@@ -378,8 +383,11 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
   const size_t num_devices = st.devices.size();
   const bool shard = num_devices > 1 && scalar_bytes >= g_shard_min_bytes.load() && cc.longest > 0;
   const generator_ref all_gens{source, generators, offset_generators};
+  // sequences longer than one pass of the engine: row ranges, like the row split below
+  const u64 max_rows = g_max_rows_per_pass.load();
+  const size_t passes = static_cast<size_t>((cc.longest + max_rows - 1) / max_rows);
 
-  if (!shard) {
+  if (!shard && passes <= 1) {
     device_state& ds = st.primary();
     std::vector<hipEvent_t> events;
     u8* d_out = enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
@@ -391,7 +399,7 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
     return;
   }
 
-  if (num_sequences >= num_devices) {
+  if (shard && num_sequences >= num_devices && passes <= 1) {
     const std::vector<unit_range> ranges = split_by_weight(column_weights(cc.cols), num_devices);
     run_on_devices(num_devices, [&](size_t k) {
       const unit_range r = ranges[k];
@@ -413,9 +421,11 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
     return;
   }
 
-  // row split
+  // row split: over the devices, and / or into passes of at most max_rows rows (a device takes
+  // every workers-th part, one after the other)
   const u32 psize = static_cast<u32>(vt.projective_size);
-  const size_t parts = row_split_parts(num_devices, cc.longest);
+  const size_t parts = std::max(row_split_parts(shard ? num_devices : 1, cc.longest), passes);
+  const size_t workers = shard ? std::min(num_devices, parts) : 1;
   device_state& root = st.primary();
   root.activate();
   const size_t partial_bytes = static_cast<size_t>(psize) * num_sequences;
@@ -424,23 +434,26 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
   u8* d_partials = st.gather.take<u8>(partial_bytes * parts);
   u8* d_final = st.gather.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
   BZ_HIP_CHECK(hipStreamSynchronize(root.stream)); // the gather buffer exists before peers write
-  run_on_devices(parts, [&](size_t k) {
-    device_state& ds = *st.devices[k];
-    const u64 row_begin = cc.longest * k / parts, row_end = cc.longest * (k + 1) / parts;
-    std::vector<host_column> mine = row_range_of(cc.cols, row_begin, row_end);
-    generator_ref g = all_gens;
-    if (g.source == generator_source::host_api) {
-      g.host_generators = static_cast<const u8*>(generators) + vt.api_generator_size * row_begin;
-    } else {
-      g.offset += row_begin;
+  run_on_devices(workers, [&](size_t w) {
+    device_state& ds = *st.devices[w];
+    for (size_t k = w; k < parts; k += workers) {
+      const u64 row_begin = static_cast<u64>(static_cast<unsigned __int128>(cc.longest) * k / parts);
+      const u64 row_end = static_cast<u64>(static_cast<unsigned __int128>(cc.longest) * (k + 1) / parts);
+      std::vector<host_column> mine = row_range_of(cc.cols, row_begin, row_end);
+      generator_ref g = all_gens;
+      if (g.source == generator_source::host_api) {
+        g.host_generators = static_cast<const u8*>(generators) + vt.api_generator_size * row_begin;
+      } else {
+        g.offset += row_begin;
+      }
+      std::vector<hipEvent_t> events;
+      u8* d_part = enqueue_commitments(st, ds, vt, std::move(mine), row_end - row_begin, g, psize,
+                                       true, events);
+      BZ_HIP_CHECK(hipMemcpyPeerAsync(d_partials + partial_bytes * k, root.device, d_part,
+                                      ds.device, partial_bytes, ds.stream));
+      BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+      for (auto& e : events) (void)hipEventDestroy(e);
     }
-    std::vector<hipEvent_t> events;
-    u8* d_part = enqueue_commitments(st, ds, vt, std::move(mine), row_end - row_begin, g, psize,
-                                     true, events);
-    BZ_HIP_CHECK(hipMemcpyPeerAsync(d_partials + partial_bytes * k, root.device, d_part, ds.device,
-                                    partial_bytes, ds.stream));
-    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
-    for (auto& e : events) (void)hipEventDestroy(e);
   });
   root.activate();
   if (projective_out) {
@@ -691,19 +704,71 @@ void handle_make_resident(multiexp_handle& h) {
 void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsigned* bit_table,
                                unsigned uniform_bits, const unsigned* lengths,
                                unsigned num_outputs, unsigned n, const u8* scalars,
-                               bool device_operands, hipStream_t caller_stream) {
+                               bool device_operands, hipStream_t caller_stream,
+                               bool record = true) {
   if (num_outputs == 0) return;
   BZ_RELEASE_ASSERT(res != nullptr, "res is null");
   api_state& st = state();
+  // An output wider than 256 bits (the reference takes any unsigned width,
+  // cbindings/blitzar_api.h:712, pippenger2/multiexponentiation.h:207-288: a bit plane per bit): the
+  // engine's columns are scalars of at most 256 bits, so such an output is computed as
+  // ceil(width / 256) adjacent columns of the same rows and folded, sum_j 2^(256 j) piece_j, with the
+  // curve's own doubling and addition (exact group arithmetic: the same point)
+  bool any_wide = false;
+  for (unsigned k = 0; k < num_outputs; ++k) {
+    any_wide = any_wide || (bit_table != nullptr ? bit_table[k] : uniform_bits) > 256;
+  }
+  if (any_wide) {
+    BZ_RELEASE_ASSERT(!device_operands,
+                      "device entry point: outputs wider than 256 bits are not supported");
+    std::vector<unsigned> piece_bits, piece_lengths;
+    std::vector<u32> piece_counts(num_outputs);
+    for (unsigned k = 0; k < num_outputs; ++k) {
+      unsigned width = bit_table != nullptr ? bit_table[k] : uniform_bits;
+      BZ_RELEASE_ASSERT(width > 0, "output bit width must be positive");
+      piece_counts[k] = (width + 255) / 256;
+      for (; width > 0; width -= std::min(width, 256u)) {
+        piece_bits.push_back(std::min(width, 256u));
+        piece_lengths.push_back(lengths != nullptr ? lengths[k] : n);
+      }
+    }
+    BZ_RELEASE_ASSERT(piece_bits.size() < (size_t{1} << 31), "too many output pieces");
+    const size_t psize = h.vt->projective_size;
+    std::vector<u8> pieces(psize * piece_bits.size());
+    // BLITZAR_DUMP_DIR records the call as the caller made it
+    std::unique_ptr<dump_recorder> recorder;
+    u64 total_bits = 0;
+    unsigned max_len = 0;
+    for (size_t i = 0; i < piece_bits.size(); ++i) {
+      total_bits += piece_bits[i];
+      max_len = std::max(max_len, piece_lengths[i]);
+    }
+    if (bit_table != nullptr && record) {
+      std::lock_guard<std::mutex> api_lock(st.api_mutex);
+      recorder = std::make_unique<dump_recorder>(lengths != nullptr ? "vlen-multiexponentiation"
+                                                                     : "packed-multiexponentiation");
+      if (recorder->recording()) {
+        recorder->write_inputs(h, bit_table, lengths, num_outputs, max_len, scalars,
+                               static_cast<size_t>((total_bits + 7) / 8) * max_len);
+      }
+    }
+    fixed_multiexponentiation(pieces.data(), h, piece_bits.data(), 0,
+                              lengths != nullptr ? piece_lengths.data() : nullptr,
+                              static_cast<unsigned>(piece_bits.size()), n, scalars, false, nullptr,
+                              false);
+    h.vt->fold_shifted_host(static_cast<u8*>(res), pieces.data(), piece_counts.data(), num_outputs,
+                            256);
+    if (recorder && recorder->recording()) {
+      recorder->write("result.bin", res, psize * num_outputs);
+    }
+    return;
+  }
   u64 total_bits = 0;
   unsigned prev_len = 0, max_len = 0;
   std::vector<host_column> cols(num_outputs);
   for (unsigned k = 0; k < num_outputs; ++k) {
     const unsigned width = bit_table != nullptr ? bit_table[k] : uniform_bits;
     BZ_RELEASE_ASSERT(width > 0, "output bit width must be positive");
-    // documented narrowing (INTEGRATION.md "Limits"): the reference accepts any unsigned width;
-    // here an output is one scalar of at most 256 bits, like every sxt_sequence_descriptor
-    BZ_RELEASE_ASSERT(width <= 256, "outputs wider than 256 bits are not supported");
     const unsigned len = lengths != nullptr ? lengths[k] : n;
     BZ_RELEASE_ASSERT(len >= prev_len, "output lengths must be sorted in ascending order");
     prev_len = len;
@@ -714,6 +779,9 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   BZ_RELEASE_ASSERT(total_bits < (u64{1} << 32), "row too wide");
   const u64 row_bytes = (total_bits + 7) / 8;
   BZ_RELEASE_ASSERT(max_len <= h.n, "more rows than generators in the handle");
+  // (a handle of 2^31 generators would need 275 GB of resident addends: bounded by memory, not by
+  // the interface)
+  BZ_RELEASE_ASSERT(max_len < (1u << 31), "fixed-base calls are limited to 2^31 - 1 rows");
   BZ_RELEASE_ASSERT(max_len == 0 || scalars != nullptr, "scalars is null");
   std::vector<u64> first_bit(num_outputs);
   for (unsigned k = 0; k < num_outputs; ++k) {
@@ -743,7 +811,7 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   // BLITZAR_DUMP_DIR: record packed / vlen calls with host operands (the plain byte-aligned entry
   // point is not recorded by the reference either, gpu_backend.cc:257-272)
   std::unique_ptr<dump_recorder> recorder;
-  if (bit_table != nullptr) {
+  if (bit_table != nullptr && record) {
     recorder = std::make_unique<dump_recorder>(lengths != nullptr ? "vlen-multiexponentiation"
                                                                    : "packed-multiexponentiation");
     if (recorder->recording()) {
@@ -1032,6 +1100,11 @@ int bzamd_num_devices(void) {
 
 void bzamd_set_shard_min_bytes(uint64_t bytes) { g_shard_min_bytes.store(bytes); }
 
+void bzamd_set_max_rows_per_pass(uint64_t rows) {
+  BZ_RELEASE_ASSERT(rows >= 1 && rows < (uint64_t{1} << 31), "rows per pass must be in [1, 2^31)");
+  g_max_rows_per_pass.store(rows);
+}
+
 void bzamd_transcript_init(struct sxt_transcript* transcript, const char* label,
                            uint64_t label_len) {
   BZ_RELEASE_ASSERT(transcript != nullptr && (label != nullptr || label_len == 0), "null argument");
@@ -1072,6 +1145,13 @@ void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
                          max_workspace_bytes);
 }
 
+void bzamd_set_window_bits(uint32_t window_bits) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "tuning applies to the GPU backend");
+  msm_context_set_window_bits(st.context_for_current_device(), window_bits);
+  for (auto& d : st.devices) msm_context_set_window_bits(d->ctx, window_bits);
+}
+
 void bzamd_set_segments(uint32_t log2_entries_per_accumulate_lane,
                         uint32_t log2_buckets_per_reduce_lane) {
   api_state& st = state();
@@ -1087,6 +1167,40 @@ void bzamd_reset_for_testing(void) {
 }
 
 namespace {
+// Device operands, sequences longer than one pass of the engine (g_max_rows_per_pass): every pass
+// commits a row range of all columns to projective partials, one fold kernel adds them up (and
+// encodes).  `d_addends` (resident set, `addend_size` bytes per row) or `d_api_generators`.
+void msm_device_in_passes(const curve_vtable& vt, msm_context* ctx, u8* out, bool projective_out,
+                          const checked_columns& cc, const void* d_addends, size_t addend_size,
+                          const void* d_api_generators, hipStream_t stream) {
+  const u64 max_rows = g_max_rows_per_pass.load();
+  const size_t passes = static_cast<size_t>((cc.longest + max_rows - 1) / max_rows);
+  const u32 psize = static_cast<u32>(vt.projective_size);
+  const u32 num_sequences = static_cast<u32>(cc.cols.size());
+  const size_t partial_bytes = static_cast<size_t>(psize) * num_sequences;
+  u8* d_partials = nullptr;
+  BZ_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_partials), partial_bytes * passes, stream));
+  for (size_t k = 0; k < passes; ++k) {
+    const u64 row_begin = static_cast<u64>(static_cast<unsigned __int128>(cc.longest) * k / passes);
+    const u64 row_end = static_cast<u64>(static_cast<unsigned __int128>(cc.longest) * (k + 1) / passes);
+    const std::vector<host_column> mine = row_range_of(cc.cols, row_begin, row_end);
+    if (d_addends != nullptr) {
+      vt.msm_resident(*ctx, d_partials + partial_bytes * k, psize, true, mine,
+                      static_cast<const u8*>(d_addends) + addend_size * row_begin, stream, nullptr);
+    } else {
+      vt.msm(*ctx, d_partials + partial_bytes * k, psize, true, mine, nullptr,
+             static_cast<const u8*>(d_api_generators) + vt.api_generator_size * row_begin, stream);
+    }
+  }
+  if (projective_out) {
+    vt.fold_device(out, d_partials, static_cast<u32>(passes), num_sequences, stream);
+  } else {
+    vt.fold_encode_device(out, d_partials, static_cast<u32>(passes), num_sequences, stream);
+  }
+  g_kernel_launches += 1;
+  BZ_HIP_CHECK(hipFreeAsync(d_partials, stream));
+}
+
 void msm_device(unsigned curve_id, void* out, uint32_t num_sequences,
                 const struct sxt_sequence_descriptor* descriptors, const void* generators,
                 void* stream, bool projective_out) {
@@ -1098,6 +1212,13 @@ void msm_device(unsigned curve_id, void* out, uint32_t num_sequences,
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
   checked_columns cc = check_descriptors(descriptors, num_sequences);
+  if (cc.longest > g_max_rows_per_pass.load()) {
+    t_pipeline_next = false; // a call of several passes completes on the caller's stream
+    msm_device_in_passes(*vt, st.context_for_current_device(), static_cast<u8*>(out),
+                         projective_out, cc, nullptr, 0, generators,
+                         static_cast<hipStream_t>(stream));
+    return;
+  }
   apply_pipeline_request(st.context_for_current_device());
   vt->msm(*st.context_for_current_device(), static_cast<u8*>(out),
           static_cast<u32>(projective_out ? vt->projective_size : vt->output_size), projective_out,
@@ -1137,6 +1258,126 @@ void bzamd_msm_projective(unsigned curve_id, void* res, uint32_t num_sequences,
   BZ_RELEASE_ASSERT(num_sequences == 0 || generators != nullptr, "generators is null");
   compute_commitments(*vt, res, num_sequences, descriptors, generators, generator_source::host_api,
                       0, true);
+}
+
+//--------------------------------------------------------------------------------------------------
+// multi-device MSM inside one process, device-resident operands, RCCL all-gather of the results
+//--------------------------------------------------------------------------------------------------
+int bzamd_device_id(int slot) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
+  BZ_RELEASE_ASSERT(slot >= 0 && static_cast<size_t>(slot) < st.devices.size(), "no such device slot");
+  return st.devices[static_cast<size_t>(slot)]->device;
+}
+
+uint32_t bzamd_multi_device_columns_per_device(uint32_t num_sequences) {
+  api_state& st = state();
+  const uint32_t d = static_cast<uint32_t>(st.devices.empty() ? 1 : st.devices.size());
+  return (num_sequences + d - 1) / d;
+}
+
+const char* bzamd_multi_device_exchange(void) {
+  api_state& st = state();
+  return st.exchange_state == 1 ? "rccl" : (st.exchange_state == 2 ? "peer-copies" : "unused");
+}
+
+void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_t num_sequences,
+                            const struct sxt_sequence_descriptor* descriptors,
+                            const void* const* generators) {
+  if (num_sequences == 0) return;
+  const curve_vtable* vt = curve_vtable_for(curve_id);
+  BZ_RELEASE_ASSERT(vt != nullptr, "unknown curve id");
+  BZ_RELEASE_ASSERT(generators != nullptr, "generators is null");
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
+  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const size_t D = st.devices.size();
+  const checked_columns cc = check_descriptors(descriptors, num_sequences);
+  const u32 out_stride = static_cast<u32>(vt->output_size);
+  const size_t per = (num_sequences + D - 1) / D; // columns per device (the last ones may be short)
+  const size_t chunk = per * out_stride;          // bytes every device contributes
+  int current = 0;
+  BZ_HIP_CHECK(hipGetDevice(&current));
+
+  // the exchange: RCCL over the devices' links, unless two slots share a physical device
+  if (st.exchange_state == 0) {
+    bool distinct = true;
+    for (size_t a = 0; a < D; ++a) {
+      for (size_t b = a + 1; b < D; ++b) distinct = distinct && st.devices[a]->device != st.devices[b]->device;
+    }
+    rccl_api* rccl = distinct ? rccl_api::get() : nullptr;
+    st.exchange_state = 2;
+    if (rccl != nullptr) {
+      std::vector<int> ids(D);
+      for (size_t d = 0; d < D; ++d) ids[d] = st.devices[d]->device;
+      std::vector<ncclComm_t> comms(D);
+      const ncclResult_t r = rccl->comm_init_all(comms.data(), static_cast<int>(D), ids.data());
+      if (r == ncclSuccess) {
+        for (auto c : comms) st.comms.push_back(c);
+        st.destroy_comm = [](void* c) {
+          if (rccl_api* api = rccl_api::get()) (void)api->comm_destroy(static_cast<ncclComm_t>(c));
+        };
+        st.exchange_state = 1;
+      } else {
+        std::fprintf(stderr, "blitzar_amd: ncclCommInitAll failed (%s); using peer copies\n",
+                     rccl->get_error_string != nullptr ? rccl->get_error_string(r) : "?");
+      }
+    }
+  }
+
+  // every device: its columns -> its piece of the send buffer (one host thread per device)
+  std::vector<u8*> send(D), recv(D);
+  run_on_devices(D, [&](size_t d) {
+    device_state& ds = *st.devices[d];
+    ds.activate();
+    ds.io.reset(device_arena::padded(chunk) + device_arena::padded(chunk * D) + 512, ds.stream);
+    send[d] = ds.io.take<u8>(chunk);
+    recv[d] = ds.io.take<u8>(chunk * D);
+    const size_t begin = std::min<size_t>(d * per, num_sequences);
+    const size_t end = std::min<size_t>(begin + per, num_sequences);
+    if (end - begin < per) BZ_HIP_CHECK(hipMemsetAsync(send[d], 0, chunk, ds.stream));
+    if (begin == end) return;
+    BZ_RELEASE_ASSERT(generators[d] != nullptr, "generators of a device that owns columns is null");
+    const std::vector<host_column> mine(cc.cols.begin() + begin, cc.cols.begin() + end);
+    vt->msm(*ds.ctx, send[d], out_stride, false, mine, nullptr, generators[d], ds.stream);
+  });
+
+  if (st.exchange_state == 1) {
+    rccl_api* rccl = rccl_api::get();
+    ncclResult_t r = rccl->group_start();
+    for (size_t d = 0; d < D && r == ncclSuccess; ++d) {
+      st.devices[d]->activate();
+      r = rccl->all_gather(send[d], recv[d], chunk, ncclUint8, static_cast<ncclComm_t>(st.comms[d]),
+                           st.devices[d]->stream);
+    }
+    const ncclResult_t e = rccl->group_end();
+    BZ_RELEASE_ASSERT(r == ncclSuccess && e == ncclSuccess, "ncclAllGather failed");
+  } else {
+    // peer copies: every piece to every device, on the stream of the device that produced it
+    // (behind its MSM); the destinations are synchronised below
+    for (size_t s = 0; s < D; ++s) {
+      device_state& src = *st.devices[s];
+      src.activate();
+      for (size_t d = 0; d < D; ++d) {
+        BZ_HIP_CHECK(hipMemcpyPeerAsync(recv[d] + chunk * s, st.devices[d]->device, send[s],
+                                        src.device, chunk, src.stream));
+      }
+    }
+  }
+  for (size_t d = 0; d < D; ++d) {
+    st.devices[d]->activate();
+    BZ_HIP_CHECK(hipStreamSynchronize(st.devices[d]->stream));
+  }
+  if (commitments != nullptr) {
+    for (size_t d = 0; d < D; ++d) {
+      if (commitments[d] == nullptr) continue;
+      st.devices[d]->activate();
+      BZ_HIP_CHECK(hipMemcpyAsync(commitments[d], recv[d], static_cast<size_t>(out_stride) * num_sequences,
+                                  hipMemcpyDeviceToDevice, st.devices[d]->stream));
+      BZ_HIP_CHECK(hipStreamSynchronize(st.devices[d]->stream));
+    }
+  }
+  BZ_HIP_CHECK(hipSetDevice(current));
 }
 
 void bzamd_fold_encode(unsigned curve_id, void* commitments, const void* partials,
@@ -1204,6 +1445,13 @@ void bzamd_msm_device_resident(void* commitments, uint32_t num_sequences,
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   BZ_RELEASE_ASSERT(cc.longest <= g->n, "sequence longer than the resident generator set");
+  if (cc.longest > g_max_rows_per_pass.load()) {
+    t_pipeline_next = false;
+    msm_device_in_passes(*g->vt, st.context_for_current_device(), static_cast<u8*>(commitments),
+                         false, cc, g->table.d_addends, g->vt->resident_addend_size, nullptr,
+                         static_cast<hipStream_t>(stream));
+    return;
+  }
   apply_pipeline_request(st.context_for_current_device());
   g->vt->msm_resident(*st.context_for_current_device(), static_cast<u8*>(commitments),
                       static_cast<u32>(g->vt->output_size), false, cc.cols, g->table.d_addends,

@@ -120,6 +120,12 @@ struct api_state {
   std::mutex api_mutex;
   size_t host_shards = 1; // SXT_CPU_BACKEND: host threads a call is split over (FORCE_SHARDS)
   device_arena gather; // on devices[0]: partial results of the other devices (row-split calls)
+  // RCCL communicators of bzamd_msm_multi_device (one per device slot, ncclCommInitAll on first
+  // use); `exchange_state`: 0 = not tried, 1 = RCCL, 2 = peer copies (logical devices sharing a
+  // physical one -- RCCL refuses duplicate devices -- or no librccl)
+  std::vector<void*> comms;
+  int exchange_state = 0;
+  void (*destroy_comm)(void*) = nullptr;
 
   // built-in ristretto generators 0 .. num_precomputed-1
   std::vector<ed_point> host_generators;  // raw extended coordinates
@@ -153,6 +159,9 @@ struct api_state {
       if (!devices.empty()) {
         (void)hipSetDevice(devices[0]->device);
         gather.release();
+      }
+      if (destroy_comm != nullptr) {
+        for (void* c : comms) destroy_comm(c);
       }
       devices.clear();
       for (auto& kv : device_contexts) {

@@ -102,6 +102,12 @@ void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_
   ctx->tuning.force_segment_log2 = log2_entries_per_accumulate_lane;
   ctx->tuning.force_reduce_segment_log2 = log2_buckets_per_reduce_lane;
 }
+void msm_context_set_window_bits(msm_context* ctx, u32 window_bits) {
+  BZ_RELEASE_ASSERT(window_bits == 0 || (window_bits >= 2 && window_bits <= 16),
+                    "window width must be 2..16 (0 = automatic)");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->tuning.force_window_bits = window_bits;
+}
 void msm_context_defer_next_tail(msm_context* ctx) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->defer_tail = true;

@@ -214,6 +214,22 @@ template <class C, class R = C, class H = C> struct curve_tu {
       C::encode(out + static_cast<u64>(k) * C::output_size, acc);
     }
   }
+  // out[k] = sum_j 2^(shift_bits j) * pieces[first_k + j] (projective elements in, projective
+  // out): an output of a fixed-base call that is wider than a scalar was computed in pieces of
+  // `shift_bits` bits (api/capi.hip); Horner from the top piece down
+  static void fold_shifted_host(u8* out, const void* pieces, const u32* piece_counts,
+                                u32 num_outputs, u32 shift_bits) {
+    u64 first = 0;
+    for (u32 k = 0; k < num_outputs; ++k) {
+      typename C::point acc = C::identity();
+      for (u32 j = piece_counts[k]; j-- > 0;) {
+        if (j + 1 != piece_counts[k]) acc = C::dbl_n(acc, static_cast<int>(shift_bits));
+        acc = C::add(acc, C::point_from_api_projective(pieces, first + j));
+      }
+      C::store_projective(out + static_cast<u64>(k) * C::projective_size, acc);
+      first += piece_counts[k];
+    }
+  }
   static void fold_encode_device(u8* d_out, const void* d_partials, u32 num_partials,
                                  u32 num_outputs, hipStream_t stream) {
     if (num_outputs == 0) return;
@@ -251,6 +267,7 @@ template <class C, class R = C, class H = C> struct curve_tu {
                                  &curve_tu::fold_encode_host,
                                  &curve_tu::fold_encode_device,
                                  &curve_tu::fold_device,
+                                 &curve_tu::fold_shifted_host,
                                  &curve_tu::generator_multiples,
                                  sizeof(typename R::addend),
                                  &curve_tu::msm_resident,

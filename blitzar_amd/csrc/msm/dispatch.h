@@ -39,6 +39,11 @@ struct curve_vtable {
   // the same sums left as raw projective elements (`projective_size` apart)
   void (*fold_device)(u8* d_out, const void* d_partials, u32 num_partials, u32 num_outputs,
                       hipStream_t stream);
+  // out[k] = sum_j 2^(shift_bits j) * pieces[first_k + j], first_k = piece_counts[0] + ... +
+  // piece_counts[k - 1]: projective elements in and out, host memory (outputs of a fixed-base call
+  // wider than one scalar)
+  void (*fold_shifted_host)(u8* out, const void* pieces, const u32* piece_counts, u32 num_outputs,
+                            u32 shift_bits);
   // d_out[i] = (i + 1) * base, C-ABI generator layout (synthetic generator sets)
   void (*generator_multiples)(void* d_out, const void* d_base_api, u64 n, hipStream_t stream);
   // resident generator sets (registered once, reused by many calls): their own addend layout
@@ -84,6 +89,8 @@ void msm_context_free(msm_context* ctx);
 // per batch of columns
 void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
                             size_t max_workspace_bytes);
+// tests: every column takes this window width where it can (0 = the cost model chooses)
+void msm_context_set_window_bits(msm_context* ctx, u32 window_bits);
 // throughput mode (bzamd_msm_device_pipelined): the next MSM enqueued on this context leaves its last
 // stage running on the context's tail stream; `join_tail` makes `stream` wait for it
 void msm_context_defer_next_tail(msm_context* ctx);

@@ -162,6 +162,7 @@ struct msm_tuning {
   // window-width cost model: from this many columns on, buckets cost `throughput_bucket_cost`
   size_t throughput_columns = 4;
   double throughput_bucket_cost = BZ_THROUGHPUT_BUCKET_COST;
+  u32 force_window_bits = 0;         // tests (bzamd_set_window_bits): this width wherever a column allows it
   u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
   u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
   // throughput mode (engine.h, msm_context::tail): calls with this many columns or more ignore
@@ -193,6 +194,10 @@ inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune, double bu
   u32 best_c = 1;
   double best_cost = 1e300;
   const u32 cmax = tune.max_window_bits < bits + 1 ? tune.max_window_bits : bits + 1;
+  if (tune.force_window_bits != 0) {
+    const u32 c = tune.force_window_bits < cmax ? tune.force_window_bits : cmax;
+    return c < 2 ? 2 : c;
+  }
   for (u32 c = 2; c <= cmax; ++c) {
     const u32 w = ceil_div_u32(bits + 1, c);
     const double cost =

@@ -41,6 +41,11 @@ int bzamd_active_backend(void);
 int bzamd_num_devices(void);
 /* calls with fewer scalar bytes than this stay on one device (default 1 MiB) */
 void bzamd_set_shard_min_bytes(uint64_t bytes);
+/* rows of a sequence one pass of the engine takes (default 2^28, at most 2^31 - 1: the engine
+ * indexes the rows of a pass with 31 bits).  A longer sequence -- the ABI's n is a uint64_t -- runs
+ * in ceil(n / rows) passes over row ranges whose projective partial results are folded; the
+ * canonical result is the same.  Tests lower it. */
+void bzamd_set_max_rows_per_pass(uint64_t rows);
 /* A fresh Merlin transcript with the application's domain-separation label: the 203 bytes a
  * caller hands to sxt_curve25519_prove_inner_product / _verify_inner_product (the reference leaves
  * their construction to the caller's Merlin implementation; Rust callers transmute
@@ -62,6 +67,10 @@ void bzamd_reset_for_testing(void);
  * windows per launch, device workspace bytes per batch).  Results never depend on them. */
 void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
                       uint64_t max_workspace_bytes);
+/* Every column takes window width `window_bits` (2..16) wherever its bit width allows, instead of
+ * the width the cost model would choose from its length (0 restores the model).  For tests: the
+ * c = 16 code paths at sizes a CPU reference finishes in seconds. */
+void bzamd_set_window_bits(uint32_t window_bits);
 /* Work per lane of the two bucket kernels, as log2 (0, the default, lets every launch choose from
  * its size): sorted entries per accumulation lane (2^3..2^10; 32 for a single column so that its
  * lanes fill the machine, up to 128 when hundreds of columns do -- every segment leaves one partial
@@ -112,6 +121,28 @@ void bzamd_pipeline_flush(void* stream);
 void bzamd_msm_device(unsigned curve_id, void* commitments, uint32_t num_sequences,
                       const struct sxt_sequence_descriptor* descriptors, const void* generators,
                       void* stream);
+
+/* Multi-device MSM inside ONE process on device-resident operands (the
+ * reference's gpu backend drives every visible device from one process too,
+ * sxt/execution/device/for_each.cc:56-82, but bounces partial results through pinned host memory).
+ * The backend drives D = bzamd_num_devices() devices; device slot d is HIP device bzamd_device_id(d)
+ * (slot 0 = the device that was current at sxt_init).  The columns are cut into contiguous ranges
+ * of per = bzamd_multi_device_columns_per_device(num_sequences) = ceil(num_sequences / D) columns:
+ * column i belongs to slot i / per, and descriptors[i].data is a DEVICE pointer on THAT device;
+ * generators[d] = the generator set (C-ABI layout) as a DEVICE pointer on slot d (may be NULL for a
+ * slot that owns no column).  Every device commits its columns; ONE all-gather of the encodings --
+ * ncclAllGather on the communicators the library creates with ncclCommInitAll on first use, RCCL
+ * over the xGMI links; librccl is loaded on that first use only -- leaves ALL num_sequences
+ * commitments on EVERY device, copied to commitments[d] (DEVICE pointer on slot d, NULL = not
+ * wanted there).  Blocking.  Logical devices that share a physical one
+ * (BLITZAR_AMD_FORCE_SHARDS; RCCL refuses duplicate devices within a communicator) exchange with
+ * peer copies instead: bzamd_multi_device_exchange() says which ("rccl" / "peer-copies"). */
+int bzamd_device_id(int slot);
+uint32_t bzamd_multi_device_columns_per_device(uint32_t num_sequences);
+const char* bzamd_multi_device_exchange(void);
+void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_t num_sequences,
+                            const struct sxt_sequence_descriptor* descriptors,
+                            const void* const* generators);
 
 /* Row-sharded MSM support (one column split by rows across GPUs):
  * the partial result of a shard as a raw projective element (sxt_ristretto255 160 B /

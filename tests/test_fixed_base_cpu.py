@@ -62,6 +62,43 @@ def test_plain_packed_vlen_match_oracle(cpu_backend, oracle, cid):
     h.close()
 
 
+@pytest.mark.parametrize("cid", [0, 2])
+def test_outputs_wider_than_256_bits(cpu_backend, oracle, cid):
+    """the reference takes any unsigned bit width per output (cbindings/blitzar_api.h:712,
+    pippenger2/multiexponentiation.h:207-288: one bit plane per bit); here such an output is
+    computed as 256-bit pieces and folded -- against the bit-plane oracle"""
+    _wide_outputs(cpu_backend, oracle, cid, 23)
+
+
+def _wide_outputs(api, oracle, cid, n):
+    from oracle import fixed_base
+    rng = np.random.default_rng(5300 + cid)
+    proj = projective_generators(oracle, cid, n)
+    table = fixed_base.PartitionTable(cid, proj, 4)
+    h = api.MultiexpHandle(cid, proj)
+    bt = [300, 8, 513, 256, 1]
+    s = rng.integers(0, 256, (n, (sum(bt) + 7) // 8), dtype=np.uint8)
+    got = h.packed_multiexponentiation(bt, n, s)
+    want = fixed_base.multiexponentiate(table, bt, n, s)
+    assert np.array_equal(canon(oracle, cid, got), canon(oracle, cid, want))
+    lengths = [0, 3, 3, n - 1, n]
+    got = h.vlen_multiexponentiation(bt, lengths, s)
+    want = fixed_base.multiexponentiate(table, bt, n, s, lengths)
+    assert np.array_equal(canon(oracle, cid, got), canon(oracle, cid, want))
+    # plain entry point with 40-byte elements
+    s = rng.integers(0, 256, (n, 80), dtype=np.uint8)
+    got = h.multiexponentiation(40, 2, n, s)
+    want = fixed_base.multiexponentiate_bytes(table, 40, 2, n, s)
+    assert np.array_equal(canon(oracle, cid, got), canon(oracle, cid, want))
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [0, 1, 3])
+def test_outputs_wider_than_256_bits_gpu(gpu_backend, oracle, cid):
+    _wide_outputs(gpu_backend, oracle, cid, 23)
+
+
 def test_known_answers_of_the_reference_tests(cpu_backend, oracle):
     """cbindings/fixed_pedersen.t.cc:51-200"""
     g = oracle.ristretto_generators(3, 7)

@@ -141,7 +141,7 @@ def test_fixed_base_golden_and_file_roundtrip(gpu_backend, oracle, curve_id, tmp
     h2.close()
 
 
-@pytest.mark.parametrize("curve_id", [0, 3])
+@pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
 def test_fixed_base_plain_packed_vlen_match_oracle(gpu_backend, oracle, curve_id):
     from oracle import fixed_base
     rng = np.random.default_rng(900 + curve_id)
@@ -616,3 +616,150 @@ def test_partition_table_built_on_device(gpu_backend, oracle, curve_id, width, n
     want = fixed_base.PartitionTable(curve_id, proj, width).file_bytes()
     assert len(data) == len(want)
     assert data == want
+
+
+#--------------------------------------------------------------------------------------------------
+# sequences longer than one pass of the engine; mid-size columns in the c = 16 regime; the synthetic
+# generator sets of the full-size checks; multi-chunk blocking calls
+#--------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("curve_id", [0, 2])
+def test_rows_in_several_passes(gpu_backend, oracle, curve_id):
+    """a sequence longer than bzamd_set_max_rows_per_pass runs as row ranges whose projective
+    partials are folded (the ABI's n is a u64, sxt/multiexp/base/exponent_sequence.h:25-42): the
+    blocking entry points with caller and built-in generators, the device entry point and the
+    resident one -- 5003 rows in passes of at most 1000 against the reference"""
+    import ctypes
+    import torch
+    api = gpu_backend
+    lib = api.load()
+    rng = np.random.default_rng(4100 + curve_id)
+    n = 5003
+    gens = util.generators_for(curve_id, n)
+    g_api = util.api_generators(curve_id, gens)
+    cols = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False),
+            (rng.integers(0, 256, (n - 1001, 7), dtype=np.uint8), False),
+            (rng.integers(0, 256, (999, 4), dtype=np.uint8), True),
+            (np.zeros((0, 8), np.uint8), False),
+            (rng.integers(0, 256, (n, 1), dtype=np.uint8), False)]
+    want = oracle.commit(curve_id, cols, gens)
+    lib.bzamd_set_max_rows_per_pass(1000)
+    try:
+        assert np.array_equal(api.compute_pedersen_commitments(curve_id, cols, generators=g_api), want)
+        if curve_id == 0:
+            off = 37
+            want_off = oracle.commit(0, cols, oracle.ristretto_generators(n, off))
+            assert np.array_equal(api.compute_pedersen_commitments(0, cols, offset_generators=off),
+                                  want_off)
+        dev = torch.device("cuda", 0)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d_gens = torch.from_numpy(np.ascontiguousarray(g_api).copy()).to(dev)
+        keep = [torch.from_numpy(np.ascontiguousarray(c).view(np.uint8).reshape(len(c), -1).copy()).to(dev)
+                for c, _ in cols]
+        desc = (api.sxt_sequence_descriptor * len(cols))()
+        for i, (c, signed) in enumerate(cols):
+            desc[i] = api.sxt_sequence_descriptor(keep[i].shape[1] if len(c) else 8, len(c),
+                                                  keep[i].data_ptr() if len(c) else None,
+                                                  1 if signed else 0)
+        out = torch.zeros((len(cols), want.shape[1]), dtype=torch.uint8, device=dev)
+        lib.bzamd_pipeline_next()  # ignored by a call of several passes
+        lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), len(cols), desc,
+                             ctypes.c_void_p(d_gens.data_ptr()), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        h = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(d_gens.data_ptr()), n, stream)
+        out.zero_()
+        lib.bzamd_msm_device_resident(ctypes.c_void_p(out.data_ptr()), len(cols), desc, h, stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        lib.bzamd_generators_free(h)
+    finally:
+        lib.bzamd_set_max_rows_per_pass(1 << 28)
+
+
+def test_sequence_of_2_31_plus_5_rows(gpu_backend, oracle):
+    """n = 2^31 + 5 (a 2 GiB column of bytes): beyond what a 31-bit row index holds, nine passes of
+    the engine against built-in generators derived on the fly.  The column is zero except for rows
+    at the pass boundaries and past 2^31, so the reference can produce the expected commitment from
+    those rows' generators alone (compute_base_element at the same indices)."""
+    api = gpu_backend
+    n = (1 << 31) + 5
+    col = np.zeros((n, 1), dtype=np.uint8)
+    rows = [0, 1, (1 << 28) - 1, 1 << 28, (1 << 30) + 12345, (1 << 31) - 1, 1 << 31, (1 << 31) + 4]
+    rng = np.random.default_rng(31)
+    vals = rng.integers(1, 256, len(rows), dtype=np.uint8)
+    col[rows, 0] = vals
+    before = api.load().bzamd_kernel_launch_count()
+    got = api.compute_pedersen_commitments(0, [(col, False)])
+    assert api.load().bzamd_kernel_launch_count() - before >= 9 * 10
+    gens = np.concatenate([oracle.ristretto_generators(1, r) for r in rows])
+    want = oracle.commit(0, [(vals.reshape(-1, 1), False)], gens)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("curve_id", [1, 2, 3])
+def test_mid_size_column_with_16_bit_windows(gpu_backend, oracle, curve_id):
+    """a 2^17-row column on ORACLE-made generators (1024 outputs of the reference's
+    generate_random_element, then the chain g_i = g_{i-1} + g_0 built with the reference's curve
+    code) with the window width pinned to 16: stored digit -32768, 2^15 buckets per window -- the
+    regime of BASELINE configs 3-5, compared with the reference MSM itself"""
+    api = gpu_backend
+    lib = api.load()
+    n = 1 << 17
+    rng = np.random.default_rng(6100 + curve_id)
+    gens = util.weierstrass_generators(curve_id, n, distinct_seeds=1024)
+    col = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    col[:, 31] &= 0x0f
+    want = oracle.commit(curve_id, [(col, False)], gens)
+    lib.bzamd_set_window_bits(16)
+    try:
+        got = api.compute_pedersen_commitments(curve_id, [(col, False)],
+                                               generators=util.api_generators(curve_id, gens))
+    finally:
+        lib.bzamd_set_window_bits(0)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("curve_id", [1, 2, 3])
+def test_generator_multiples_match_reference_additions(gpu_backend, oracle, curve_id):
+    """bzamd_generator_multiples_device (the synthetic generator sets g_i = (i + 1) G of the
+    full-size checks of configs 3-5) against the chain G, G + G, ... built with the reference's own
+    addition, for the first 300 rows"""
+    import ctypes
+    import torch
+    lib = gpu_backend.load()
+    dev = torch.device("cuda", 0)
+    _, nl, stride, _ = oracle.CURVES[curve_id]
+    base = oracle.random_affine(curve_id, 1, 2)
+    n = 300
+    d_base = torch.from_numpy(np.ascontiguousarray(base).view(np.uint8).reshape(-1).copy()).to(dev)
+    out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    lib.bzamd_generator_multiples_device(curve_id, ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_void_p(d_base.data_ptr()), n, None)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    g0 = oracle.affine_to_projective(curve_id, base.reshape(1, -1))[0]
+    acc = g0
+    for i in range(n):
+        if i:
+            acc = oracle.add_projective(curve_id, acc, g0)
+        want = np.ascontiguousarray(oracle.to_affine(curve_id, acc)).view(np.uint8).reshape(-1)
+        assert np.array_equal(got[i, :16 * nl], want[:16 * nl]) and got[i, 16 * nl] == 0, f"row {i}"
+
+
+def test_blocking_call_of_two_chunks_bn254(gpu_backend, oracle):
+    """host buffers are uploaded in chunks of 48 MiB of scalars while the engine works on the
+    previous chunk, and the chunks of a call run in throughput mode among themselves: two 2^20-row
+    bn254 columns of 32-byte elements and a short one = two chunks, against the reference (24-bit
+    values: the reference's cost follows the bit width; 16 distinct generators repeated)"""
+    api = gpu_backend
+    n = 1 << 20
+    rng = np.random.default_rng(254)
+    gens = np.tile(util.weierstrass_generators(2, 16, distinct_seeds=16), (n // 16, 1))
+    cols = []
+    for rows in (n, n, 1000):
+        c = np.zeros((rows, 32), dtype=np.uint8)
+        c[:, :3] = rng.integers(0, 256, (rows, 3), dtype=np.uint8)
+        cols.append((c, False))
+    want = oracle.commit(2, cols, gens)
+    got = api.compute_pedersen_commitments(2, cols, generators=util.api_generators(2, gens))
+    assert np.array_equal(got, want)

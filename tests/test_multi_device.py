@@ -155,3 +155,59 @@ def test_split_by_weight_is_a_partition():
         outs.append(next(ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")))
     assert len(set(outs)) == 1
     _ = (api, cols)
+
+
+MD_CHECK = os.path.join(ROOT, "tools", "pipeline_bench", "_build", "multi_device_check")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [1, 3, 8])
+def test_msm_multi_device_native_check(shards):
+    """bzamd_msm_multi_device (columns sharded over the devices one process drives, all-gather of the
+    commitments) and the sharded blocking entry points against the same work confined to device 0,
+    through the native self-check bench.py also runs on a multi-GPU node.  One visible GPU: a
+    single rank exchanges through RCCL (ncclCommInitAll + ncclAllGather really run: librccl is
+    loaded, the communicator built); logical devices exchange with peer copies (RCCL refuses a
+    communicator with duplicate devices)."""
+    assert os.path.exists(MD_CHECK), "build() compiles tools/pipeline_bench/multi_device_check"
+    env = dict(os.environ)
+    env.pop("BLITZAR_AMD_NUM_DEVICES", None)
+    if shards > 1:
+        env["BLITZAR_AMD_FORCE_SHARDS"] = str(shards)
+    else:
+        env["BLITZAR_AMD_NUM_DEVICES"] = "1"
+    r = subprocess.run([MD_CHECK, "--log2n", "14", "--columns", "11", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ok"] and line["devices"] == shards
+    assert line["exchange"] == ("rccl" if shards == 1 else "peer-copies"), line
+
+
+@pytest.mark.gpu
+def test_msm_multi_device_matches_oracle(gpu_backend, oracle):
+    """the multi-device entry point itself against the reference (one device here: the column
+    ranges, the padded send buffer and the RCCL exchange with a single rank)"""
+    import ctypes
+    import torch
+    api = gpu_backend
+    lib = api.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    for cid, n in ((0, 3000), (2, 1500)):
+        gens = util.generators_for(cid, n)
+        d_gens = torch.from_numpy(np.ascontiguousarray(util.api_generators(cid, gens)).copy()).to(dev)
+        cols = [rng.integers(0, 256, (n - 5 * c, 32 if c % 2 == 0 else 7), dtype=np.uint8)
+                for c in range(5)]
+        want = oracle.commit(cid, [(c, False) for c in cols], gens)
+        d_cols = [torch.from_numpy(c.copy()).to(dev) for c in cols]
+        desc = (api.sxt_sequence_descriptor * len(cols))()
+        for i, c in enumerate(cols):
+            desc[i] = api.sxt_sequence_descriptor(c.shape[1], c.shape[0], d_cols[i].data_ptr(), 0)
+        out = torch.zeros((len(cols), want.shape[1]), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        D = lib.bzamd_num_devices()
+        outs = (ctypes.c_void_p * D)(*([out.data_ptr()] + [None] * (D - 1)))
+        gptr = (ctypes.c_void_p * D)(*([d_gens.data_ptr()] * D))
+        lib.bzamd_msm_multi_device(cid, outs, len(cols), desc, gptr)
+        assert np.array_equal(out.cpu().numpy(), want)
