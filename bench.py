@@ -543,6 +543,22 @@ def main():
         if world > 1:
             coll.all_gather(gathered, outs)
 
+    # untimed passes first (they used to follow the timed region; ahead of it the GPU enters the W
+    # warmup steps and the K timed steps at its sustained clocks, as in a service under load): the
+    # six stage times and the latency of a lone call with plain stream semantics (no throughput mode)
+    stage_steps = min(args.steps, 50)
+    clock = StageClock(lib, stage_steps)
+    for _ in range(stage_steps):
+        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
+    torch.cuda.synchronize()
+    per_call, _ = clock.collect(stage_steps)
+    t_single = time.perf_counter()
+    for _ in range(stage_steps):
+        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
+    torch.cuda.synchronize()
+    single_call_ms = 1e3 * (time.perf_counter() - t_single) / stage_steps
+
+    lone_output = out.cpu().numpy().copy()
     for k in range(args.warmup):
         step(k)
     if args.warmup:
@@ -568,6 +584,8 @@ def main():
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
+    per_call["accumulate"] = timed_stages["accumulate"]
+    assert np.array_equal(lone_output, timed_output), "lone call disagrees with the sequence"
     dist_info = None
     if world > 1:
         everyone = gathered.cpu().numpy().reshape(world, max_steps, 32)[:, :args.steps]
@@ -593,21 +611,6 @@ def main():
             "distinct_devices": len({(p["device_index"], p["pci_bus_id"]) for p in peers}),
         }
         assert args.dry_run_one_gpu or dist_info["distinct_commitments_gathered"] == world
-    # untimed passes: the six stage times, and the latency of a lone call (no throughput mode)
-    stage_steps = min(args.steps, 50)
-    clock = StageClock(lib, stage_steps)
-    for _ in range(stage_steps):
-        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
-    torch.cuda.synchronize()
-    per_call, _ = clock.collect(stage_steps)
-    per_call["accumulate"] = timed_stages["accumulate"]
-    t_single = time.perf_counter()
-    for _ in range(stage_steps):
-        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
-    torch.cuda.synchronize()
-    single_call_ms = 1e3 * (time.perf_counter() - t_single) / stage_steps
-    assert np.array_equal(out.cpu().numpy(), timed_output), "lone call disagrees with the sequence"
-
     # informational second leg (single-GPU run): the same step with the generators registered once
     # as a resident set (bzamd_generators_*).  Never used for `value`.
     resident_ms = None

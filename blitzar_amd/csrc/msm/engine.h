@@ -127,38 +127,43 @@ struct msm_context {
   // stage that read it (k_horner, two batches ago) has finished.
   //
   // Throughput mode (bzamd_pipeline_next; batch = one launch sequence, a call of a few columns is
-  // one batch).  A batch has four stages with complementary bottlenecks:
-  //   front      conversion of caller generators, recoding, the two-pass bucket sort: nine short
-  //              HBM-bound kernels (0.2-0.3 ms at 2^20 curve25519 rows, ~0.64 GB moved);
-  //   accumulate the bucket additions: integer-issue bound, every SIMD full (0.7 ms);
+  // one batch).  A batch has four stages:
+  //   front      conversion of caller generators, recoding, the two-pass bucket sort: short kernels
+  //              (0.2-0.3 ms at 2^20 curve25519 rows, ~0.64 GB moved);
+  //   accumulate the bucket additions: integer-issue bound, every SIMD full (0.65-0.7 ms);
   //   reduce     bucket reduction: a latency chain at one wavefront per SIMD (0.2-0.3 ms);
   //   horner     ONE workgroup per column, ~250 dependent doublings + the encoding (0.2-0.4 ms).
-  // In a sequence of same-shaped calls every stage gets a stream of its own and batch k + 1's front
-  // runs beside batch k's accumulation, whose reduce and horner run beside batch k + 1's
-  // accumulation: a step then costs about max(stage) instead of their sum.  The buffers a stage
-  // writes while an earlier batch's later stage still reads exist more than once, indexed by the
-  // batch's sequence number: everything the front writes and the accumulation reads (addends,
-  // digits, records, sorted entries, group tables, segment map) twice; the bucket ends (written by
-  // the sort, read by accumulate AND reduce) three times; what accumulate / reduce / horner hand
-  // on (bucket sums, head partials, partials, entry counts, chain state) twice.  Completion marks
-  // (rings of 4 events) order a stage behind the stage of an earlier batch whose buffers it reuses.
-  //   * The caller's stream only carries waits: at entry the front stream waits for it (the
-  //     operands are ready), at the end of the call it waits for the batch's front (the operands
-  //     have been consumed: the caller may overwrite them in stream order) and for the PREVIOUS
-  //     batch's horner, so a result is complete on the stream once the next call has been enqueued
-  //     or after bzamd_pipeline_flush.
-  //   * k_accumulate owns every SIMD's registers (3 waves x 168 VGPRs), so kernels of another
-  //     stream only get a slot when one of its workgroups retires, and the sort's 1024-lane
-  //     workgroups need a whole CU's worth at once: the front stream and the accumulation stream
-  //     therefore get disjoint CU masks (`front_cus` CUs for the front, spread evenly over the 8
-  //     XCDs: KFD deals mask bit i to XCC i mod 8); the two tail kernels are single-wave-per-SIMD
-  //     workgroups that slot in anywhere and raise their wave priority (s_setprio).
-  //   * Only while consecutive batches carve the arena identically (same shapes, curve, mode:
-  //     `pipe_layout`); any other call first joins everything pending, and so does a re-allocation
-  //     of the arena, a call outside the mode and bzamd_pipeline_flush.
-  // BLITZAR_AMD_OVERLAP_FRONT=0 keeps front and accumulation on the caller's stream (round 2's
-  // form: only the tails overlap); BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.
-  // A lone call never forks (every fork / join pair costs ~25 us of stream bubbles).
+  // In a sequence of same-shaped calls the two tail stages run on streams of their own, beside the
+  // front and the accumulation of the NEXT batch (they are tiny grids that slot in anywhere and
+  // raise their wave priority, s_setprio): a step costs front + accumulate instead of the sum of
+  // all four.  The buffers a stage writes while an earlier batch's later stage still reads exist
+  // more than once, indexed by the batch's sequence number; completion marks (rings of 4 events)
+  // order a stage behind the stage of an earlier batch whose buffers it reuses.
+  //
+  // The same machinery can put the front and the accumulation on streams of their own as well
+  // (`overlap_front`, BLITZAR_AMD_OVERLAP_FRONT=1: front of batch k + 1 beside accumulation k; then
+  // everything the front writes exists twice and the bucket ends three times).  Measured on MI355X
+  // (round 3, profiles/round3_ab_front_*.log, round3_timeline_*.txt) and OFF by default:
+  //   * two big grids of one priority level do not run concurrently at all: the second kernel's
+  //     workgroups are dispatched when the first grid has been handed out completely (1.03 ms per
+  //     step against 1.00: only the extra events show);
+  //   * disjoint CU masks (`front_cus` CUs for the front, spread over the XCDs: KFD deals mask bit i
+  //     to XCC i mod 8) do run concurrently, but the front is not HBM-bound -- its kernels need
+  //     their share of the CUs' LDS-atomic and issue rate: on 32 CUs it takes 1.06 ms instead of
+  //     0.26 and becomes the bottleneck (1.13 ms per step; 64 CUs: 1.07);
+  //   * a high-priority queue for the front (`front_high_priority`) does interleave on shared CUs
+  //     (0.94 ms per step in a process of its own) but the accumulation slows by what the front
+  //     takes (0.65 -> 0.88 ms), and under PyTorch's 32-stream pool it gains nothing (1.09 against
+  //     1.08): not worth a mode that depends on how a process's queues are laid out.
+  //   * The caller's stream only carries waits in that mode: at entry the front stream waits for it
+  //     (the operands are ready), at the end of the call it waits for the batch's front (the
+  //     operands have been consumed).
+  // Either way a pipelined result is complete on the caller's stream once two further calls have
+  // been enqueued, or after bzamd_pipeline_flush.  Only while consecutive batches carve the arena
+  // identically (same shapes, curve, mode: `pipe_layout`); any other call first joins everything
+  // pending, and so does a re-allocation of the arena, a call outside the mode and a flush.
+  // BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.  A lone call never forks (every
+  // fork / join pair costs ~25 us of stream bubbles).
   hipStream_t front = nullptr, acc = nullptr, tail = nullptr, tail2 = nullptr;
   bool pipe_streams_made = false;
   stage_mark entry;
@@ -169,7 +174,7 @@ struct msm_context {
   u64 pipe_layout = 0;        // layout tag of the pending batches
   bool defer_tail = false;    // the next call runs in throughput mode (msm_context_defer_next_tail)
   bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: never fork
-  bool overlap_front = true;  // BLITZAR_AMD_OVERLAP_FRONT=0: front + accumulation on the caller's stream
+  bool overlap_front = false; // BLITZAR_AMD_OVERLAP_FRONT=1: front + accumulation on streams of their own
   bool two_tail_streams = true; // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
   u32 front_cus = 0;          // BLITZAR_AMD_FRONT_CUS: CUs reserved for the front stream (0: no masks)
   bool front_high_priority = true; // BLITZAR_AMD_FRONT_PRIORITY=0: the front's queue at normal priority
@@ -190,18 +195,50 @@ struct msm_context {
     const size_t target = size_t{160} * 1024 / (allowed + 1) + 1024;
     return have >= target ? 0 : target - have;
   }
+  // A stream with a hardware queue of its own.  The HIP runtime multiplexes the streams of a process
+  // over a few hardware queues per priority level (4 by default), and packets of one queue execute
+  // in order: an internal stream that lands on the queue of another one (a process with many
+  // streams: PyTorch creates 32 at its first side stream) inherits that stream's waits, and the
+  // stages the mode is meant to overlap serialise again (measured: 1.12 -> 1.48 ms per step under
+  // torch).  A stream created with a CU mask -- here the mask of ALL CUs -- always gets a queue of its
+  // own.  (Such streams are blocking streams: work on the NULL stream synchronises with them.)
+  bool dedicated_queues = true; // BLITZAR_AMD_DEDICATED_QUEUES=0: plain non-blocking streams
+  bool fast_recode = true;      // BLITZAR_AMD_FAST_RECODE=0: the generic recode kernel for every shape
+  bool fuse_prepare = true;     // BLITZAR_AMD_FUSE_PREPARE=0: generator conversion in a launch of its own
+  hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
+    hipStream_t s = nullptr;
+    if (mask != nullptr || dedicated_queues) {
+      std::vector<uint32_t> all;
+      if (mask == nullptr) {
+        int device = 0, cus = 0;
+        BZ_HIP_CHECK(hipGetDevice(&device));
+        BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        all.assign((static_cast<u32>(cus) + 31) / 32, 0);
+        for (u32 i = 0; i < static_cast<u32>(cus); ++i) all[i / 32] |= 1u << (i % 32);
+        mask = &all;
+      }
+      if (hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(mask->size()), mask->data()) ==
+          hipSuccess) {
+        return s;
+      }
+      (void)hipGetLastError();
+    }
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+  }
   void make_pipe_streams() {
     if (pipe_streams_made) return;
     pipe_streams_made = true;
-    BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail, hipStreamNonBlocking));
-    BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail2, hipStreamNonBlocking));
+    tail = make_stream();
+    tail2 = make_stream();
     if (!overlap_front) return;
     int device = 0, cus = 0;
     BZ_HIP_CHECK(hipGetDevice(&device));
     BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     if (front_cus != 0 && cus >= 64 && front_cus * 2 <= static_cast<u32>(cus)) {
-      // mask bit i -> XCC i mod 8 (kfd mqd_symmetrically_map_cu_mask): a contiguous range of
-      // bits is spread evenly over the XCDs
+      // disjoint CU sets (measured and rejected as the default: the front is CU-bound, not
+      // HBM-bound -- DESIGN.md section 7d).  Mask bit i -> XCC i mod 8 (kfd
+      // mqd_symmetrically_map_cu_mask): a contiguous range of bits is spread evenly over the XCDs
       const u32 words = (static_cast<u32>(cus) + 31) / 32;
       std::vector<uint32_t> fm(words, 0), am(words, 0);
       const u32 split = static_cast<u32>(cus) - front_cus;
@@ -209,23 +246,18 @@ struct msm_context {
         (i >= split ? fm : am)[i / 32] |= 1u << (i % 32);
         if (!acc_masked) am[i / 32] |= 1u << (i % 32);
       }
-      if (hipExtStreamCreateWithCUMask(&front, words, fm.data()) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&acc, words, am.data()) == hipSuccess) {
-        return;
-      }
-      (void)hipGetLastError();
-      std::fprintf(stderr, "blitzar_amd: CU-masked streams unavailable, using plain streams\n");
-      if (front != nullptr) (void)hipStreamDestroy(front);
-      front = acc = nullptr;
+      front = make_stream(&fm);
+      acc = make_stream(&am);
+      return;
     }
     if (front_high_priority) {
       int least = 0, greatest = 0;
       BZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
       BZ_HIP_CHECK(hipStreamCreateWithPriority(&front, hipStreamNonBlocking, greatest));
     } else {
-      BZ_HIP_CHECK(hipStreamCreateWithFlags(&front, hipStreamNonBlocking));
+      front = make_stream();
     }
-    BZ_HIP_CHECK(hipStreamCreateWithFlags(&acc, hipStreamNonBlocking));
+    acc = make_stream();
   }
   bool any_pending() const { return joined < seq; }
   // make `stream` wait for every pipelined batch enqueued so far (k_horner runs on ONE stream, in
@@ -636,12 +668,26 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
   // sharing CUs with the accumulation (no masks): cap the front's waves per SIMD
   const bool capped = mode.split && ctx.front_cus == 0;
-  if (d_addends == nullptr) {
+  // caller generators: converted inside the group sort's launch (k_group_sort_prepare), or by a
+  // launch of their own (curves whose conversion shares inversions across a workgroup)
+  const bool fuse_prepare = d_addends == nullptr && !C::has_batched_prepare && ctx.fuse_prepare &&
+                            plan.max_rows != 0;
+  if (d_addends == nullptr && !fuse_prepare) {
     ctx.timer.timed(timing, 0, fs, [&] {
       launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
     });
   }
   const u64 zero_words = plan.total_groups + 1; // group cursors, cleared by the recode kernel
+  // the common shape has a recode kernel of its own: byte-aligned unsigned 32-byte scalars,
+  // 16-bit windows, one task per window (grid.y = columns)
+  bool rows32_c16 = num_cols <= 65535;
+  for (const column_desc& c : plan.columns) {
+    rows32_c16 = rows32_c16 &&
+                 (c.n == 0 || (c.bit_offset == 0 && c.bit_width == 256 && c.row_stride == 32 &&
+                               c.is_signed == 0 && c.merged_stride == 0 && c.window_bits == 16 &&
+                               c.num_windows == 17 &&
+                               (reinterpret_cast<uintptr_t>(c.data) & 15) == 0));
+  }
   ctx.timer.timed(timing, 1, fs, [&] {
     if (d_ranges != nullptr) {
       hipLaunchKernelGGL(k_recode_packed,
@@ -653,6 +699,12 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       return;
     }
     const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
+    if (rows32_c16 && ctx.fast_recode) {
+      hipLaunchKernelGGL(k_recode_rows32_c16, dim3(chunks, num_cols), dim3(256),
+                         ctx.front_lds_pad(capped, 256, 0), fs, b.digits, b.cols, b.tasks,
+                         b.group_cursor, zero_words);
+      return;
+    }
     const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
     const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
     hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256),
@@ -680,10 +732,27 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                          dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
-    hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads),
-                       ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
-                       b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
-                       b.group_chunk, b.tasks);
+    const u64 sort_blocks = static_cast<u64>(plan.max_task_groups) * num_tasks;
+    const u32 prepare_blocks = ceil_div_u32(plan.max_rows, kGroupSortThreads);
+    if (fuse_prepare && sort_blocks + prepare_blocks < (u64{1} << 31)) {
+      hipLaunchKernelGGL((k_group_sort_prepare<C>),
+                         dim3(static_cast<u32>(sort_blocks) + prepare_blocks),
+                         dim3(kGroupSortThreads),
+                         ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
+                         b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                         b.group_chunk, b.tasks, plan.max_task_groups,
+                         static_cast<u32>(sort_blocks), const_cast<addend*>(b.addends),
+                         d_api_generators, plan.max_rows, prepare_blocks);
+    } else {
+      if (fuse_prepare) {
+        launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
+      }
+      hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks),
+                         dim3(kGroupSortThreads),
+                         ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
+                         b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                         b.group_chunk, b.tasks);
+    }
     // oversized groups (skewed digits); both launches find nothing to do on uniform data
     hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
                        b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,

@@ -275,6 +275,39 @@ static __global__ void __launch_bounds__(256)
   }
 }
 
+// k_recode for the common shape: byte-aligned unsigned 32-byte scalars, 16-bit windows, one task
+// per window (the Pedersen entry points at 2^17 rows and more).  The generic kernel walks a bit
+// cursor through a register array with run-time indices, which hipcc parks in LDS (14 KiB per
+// workgroup, a dozen LDS round trips per digit: 35-50 us for 2^20 rows); here the sixteen 16-bit
+// halves of the eight words ARE the raw digits, the carry chain is unrolled, and the tasks of a
+// column lie `(n + 7) & ~7` entries apart, so nothing is looked up per window.  The stored value
+// E = -D is the low half of -(raw + carry): D = t for t <= 2^15, t - 2^16 above.
+static __global__ void __launch_bounds__(256)
+    k_recode_rows32_c16(i16* __restrict__ digits, const column_desc* __restrict__ columns,
+                        const task_desc* __restrict__ tasks, u32* __restrict__ zero, u64 zero_words) {
+  const u64 threads = static_cast<u64>(gridDim.x) * gridDim.y * blockDim.x;
+  for (u64 i = (static_cast<u64>(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+       i < zero_words; i += threads) {
+    zero[i] = 0; // the sort's group cursors (see k_recode)
+  }
+  const column_desc col = columns[blockIdx.y];
+  const u64 row = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (row >= col.n) return;
+  const uint4* src = reinterpret_cast<const uint4*>(col.data + row * 32);
+  const uint4 lo = src[0], hi = src[1];
+  const u32 words[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const u64 stride = (col.n + 7) & ~u64{7};
+  i16* dst = digits + tasks[col.first_task].entry_base + row;
+  u32 carry = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const u32 t = ((words[w >> 1] >> (16 * (w & 1))) & 0xffffu) + carry;
+    carry = t > 32768u ? 1u : 0u;
+    dst[w * stride] = static_cast<i16>(0u - t);
+  }
+  dst[16 * stride] = static_cast<i16>(0u - carry);
+}
+
 // k_recode for the packed fixed-base calls (cbindings/blitzar_api.h:688-712): the columns are bit
 // fields of the same rows, `row_stride` (~12 KiB at BASELINE configs[4]) apart, so a lane per row
 // touches one cache line per row and column and uses a few bytes of it.  Here a workgroup takes 64
@@ -638,16 +671,14 @@ constexpr u32 kBigSortBlocks = 128; // grid of the two oversized-group launches 
 static_assert(kLocalSortPerThread * kGroupSortThreads == kLocalSortCapacity);
 static_assert(2 * kGroupSortThreads >= (1u << kMaxGroupBits));
 
-static __global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                 u32* __restrict__ bucket_end, const u32* __restrict__ records,
-                 const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                 const task_desc* __restrict__ tasks) {
+__device__ __forceinline__ void
+group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
+                 u32* __restrict__ segment_bucket, u32* __restrict__ bucket_end,
+                 const u32* __restrict__ records, const u32* __restrict__ group_start,
+                 const u32* __restrict__ group_chunk) {
   __shared__ u32 cursor[1u << kMaxGroupBits];
   __shared__ u32 staging[kLocalSortCapacity];
   __shared__ u32 wave_sums[kGroupSortThreads / 64];
-  const task_desc task = tasks[blockIdx.y];
-  const u32 g = blockIdx.x;
   if (g >= task.num_groups) return;
   const u32* gc = group_chunk + task.group_base;
   if (gc[g + 1] != gc[g]) return; // oversized: k_group_big_hist / k_group_big_sort
@@ -762,6 +793,48 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       }
     }
   }
+}
+
+static __global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                 u32* __restrict__ bucket_end, const u32* __restrict__ records,
+                 const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                 const task_desc* __restrict__ tasks) {
+  const task_desc task = tasks[blockIdx.y];
+  group_sort_block(blockIdx.x, task, sorted, segment_bucket, bucket_end, records, group_start,
+                   group_chunk);
+}
+
+// k_group_sort and the conversion of caller generators in ONE launch.  The addends are first read
+// by k_accumulate, so their conversion can run anywhere in the front; alone it is the one kernel of
+// the front that saturates HBM (288 B per generator at 4.6 TB/s, 63 us for 2^20), while the group
+// sort is bound by LDS atomics and latency and leaves most of the bandwidth idle (140 MB in 68 us).
+// Two launches of one stream never overlap and two streams of one priority serialise at grid
+// granularity, so the workgroups of both are dealt into one grid -- `prepare`
+// blocks (kGroupSortThreads generators each, no LDS) evenly between the `sort` blocks -- and share
+// every CU: the conversion disappears behind the sort.
+template <class C>
+__global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_sort_prepare(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                         u32* __restrict__ bucket_end, const u32* __restrict__ records,
+                         const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                         const task_desc* __restrict__ tasks, u32 groups_per_task, u32 sort_blocks,
+                         typename C::addend* __restrict__ addends,
+                         const void* __restrict__ api_generators, u64 num_generators,
+                         u32 prepare_blocks) {
+  const u64 total = static_cast<u64>(sort_blocks) + prepare_blocks;
+  const u64 i = blockIdx.x;
+  const u32 prepared_before = static_cast<u32>(i * prepare_blocks / total);
+  const u32 prepared_after = static_cast<u32>((i + 1) * prepare_blocks / total);
+  if (prepared_after != prepared_before) {
+    const u64 row = static_cast<u64>(prepared_before) * kGroupSortThreads + threadIdx.x;
+    if (row < num_generators) addends[row] = C::make_addend(api_generators, row);
+    return;
+  }
+  const u32 s = static_cast<u32>(i) - prepared_before;
+  const task_desc task = tasks[s / groups_per_task];
+  group_sort_block(s % groups_per_task, task, sorted, segment_bucket, bucket_end, records,
+                   group_start, group_chunk);
 }
 
 // The oversized group that chunk `index` (counted over all oversized groups of the task) belongs

@@ -653,11 +653,11 @@ def test_rows_in_several_passes(gpu_backend, oracle, curve_id):
         dev = torch.device("cuda", 0)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         d_gens = torch.from_numpy(np.ascontiguousarray(g_api).copy()).to(dev)
-        keep = [torch.from_numpy(np.ascontiguousarray(c).view(np.uint8).reshape(len(c), -1).copy()).to(dev)
-                for c, _ in cols]
+        keep = [torch.from_numpy(np.ascontiguousarray(c).view(np.uint8).reshape(len(c), c.shape[1])
+                                 .copy()).to(dev) for c, _ in cols]
         desc = (api.sxt_sequence_descriptor * len(cols))()
         for i, (c, signed) in enumerate(cols):
-            desc[i] = api.sxt_sequence_descriptor(keep[i].shape[1] if len(c) else 8, len(c),
+            desc[i] = api.sxt_sequence_descriptor(c.shape[1], len(c),
                                                   keep[i].data_ptr() if len(c) else None,
                                                   1 if signed else 0)
         out = torch.zeros((len(cols), want.shape[1]), dtype=torch.uint8, device=dev)
