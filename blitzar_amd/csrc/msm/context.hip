@@ -63,7 +63,6 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_ACC_MASKED", ctx->acc_masked);
   flag("BLITZAR_AMD_DEDICATED_QUEUES", ctx->dedicated_queues);
   flag("BLITZAR_AMD_FAST_RECODE", ctx->fast_recode);
-  flag("BLITZAR_AMD_FUSE_PREPARE", ctx->fuse_prepare);
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");

@@ -204,7 +204,6 @@ struct msm_context {
   // own.  (Such streams are blocking streams: work on the NULL stream synchronises with them.)
   bool dedicated_queues = true; // BLITZAR_AMD_DEDICATED_QUEUES=0: plain non-blocking streams
   bool fast_recode = true;      // BLITZAR_AMD_FAST_RECODE=0: the generic recode kernel for every shape
-  bool fuse_prepare = true;     // BLITZAR_AMD_FUSE_PREPARE=0: generator conversion in a launch of its own
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
     hipStream_t s = nullptr;
     if (mask != nullptr || dedicated_queues) {
@@ -668,11 +667,10 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
   // sharing CUs with the accumulation (no masks): cap the front's waves per SIMD
   const bool capped = mode.split && ctx.front_cus == 0;
-  // caller generators: converted inside the group sort's launch (k_group_sort_prepare), or by a
-  // launch of their own (curves whose conversion shares inversions across a workgroup)
-  const bool fuse_prepare = d_addends == nullptr && !C::has_batched_prepare && ctx.fuse_prepare &&
-                            plan.max_rows != 0;
-  if (d_addends == nullptr && !fuse_prepare) {
+  // caller generators -> addends.  (Dealing this kernel's workgroups into the group sort's launch --
+  // the one HBM-saturating kernel of the front inside the LDS-bound one -- was built and measured in
+  // round 3: sort + conversion 0.171 -> 0.183 ms, profiles/round3_ab_front_fusion.log; removed.)
+  if (d_addends == nullptr) {
     ctx.timer.timed(timing, 0, fs, [&] {
       launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
     });
@@ -732,27 +730,10 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                          dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
-    const u64 sort_blocks = static_cast<u64>(plan.max_task_groups) * num_tasks;
-    const u32 prepare_blocks = ceil_div_u32(plan.max_rows, kGroupSortThreads);
-    if (fuse_prepare && sort_blocks + prepare_blocks < (u64{1} << 31)) {
-      hipLaunchKernelGGL((k_group_sort_prepare<C>),
-                         dim3(static_cast<u32>(sort_blocks) + prepare_blocks),
-                         dim3(kGroupSortThreads),
-                         ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
-                         b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
-                         b.group_chunk, b.tasks, plan.max_task_groups,
-                         static_cast<u32>(sort_blocks), const_cast<addend*>(b.addends),
-                         d_api_generators, plan.max_rows, prepare_blocks);
-    } else {
-      if (fuse_prepare) {
-        launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
-      }
-      hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks),
-                         dim3(kGroupSortThreads),
-                         ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
-                         b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
-                         b.group_chunk, b.tasks);
-    }
+    hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads),
+                       ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
+                       b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                       b.group_chunk, b.tasks);
     // oversized groups (skewed digits); both launches find nothing to do on uniform data
     hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
                        b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,

@@ -805,38 +805,6 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
                    group_chunk);
 }
 
-// k_group_sort and the conversion of caller generators in ONE launch.  The addends are first read
-// by k_accumulate, so their conversion can run anywhere in the front; alone it is the one kernel of
-// the front that saturates HBM (288 B per generator at 4.6 TB/s, 63 us for 2^20), while the group
-// sort is bound by LDS atomics and latency and leaves most of the bandwidth idle (140 MB in 68 us).
-// Two launches of one stream never overlap and two streams of one priority serialise at grid
-// granularity, so the workgroups of both are dealt into one grid -- `prepare`
-// blocks (kGroupSortThreads generators each, no LDS) evenly between the `sort` blocks -- and share
-// every CU: the conversion disappears behind the sort.
-template <class C>
-__global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_sort_prepare(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                         u32* __restrict__ bucket_end, const u32* __restrict__ records,
-                         const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                         const task_desc* __restrict__ tasks, u32 groups_per_task, u32 sort_blocks,
-                         typename C::addend* __restrict__ addends,
-                         const void* __restrict__ api_generators, u64 num_generators,
-                         u32 prepare_blocks) {
-  const u64 total = static_cast<u64>(sort_blocks) + prepare_blocks;
-  const u64 i = blockIdx.x;
-  const u32 prepared_before = static_cast<u32>(i * prepare_blocks / total);
-  const u32 prepared_after = static_cast<u32>((i + 1) * prepare_blocks / total);
-  if (prepared_after != prepared_before) {
-    const u64 row = static_cast<u64>(prepared_before) * kGroupSortThreads + threadIdx.x;
-    if (row < num_generators) addends[row] = C::make_addend(api_generators, row);
-    return;
-  }
-  const u32 s = static_cast<u32>(i) - prepared_before;
-  const task_desc task = tasks[s / groups_per_task];
-  group_sort_block(s % groups_per_task, task, sorted, segment_bucket, bucket_end, records,
-                   group_start, group_chunk);
-}
-
 // The oversized group that chunk `index` (counted over all oversized groups of the task) belongs
 // to: the largest g with chunk_first[g] <= index; groups that fit one workgroup repeat the value
 // of their successor, so the search lands on an oversized one.
