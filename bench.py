@@ -586,36 +586,35 @@ def main():
     single_call_ms = 1e3 * (time.perf_counter() - t_single) / stage_steps
 
     lone_output = out.cpu().numpy().copy()
-    # informational second leg (single-GPU run), also ahead of the timed region: the same step with
-    # the generators registered once as a resident set (bzamd_generators_*).
-    # Never used for `value`.
+    # informational second leg (every rank runs it, rank 0 of a single-GPU run reports it), also
+    # ahead of the timed region: the same step with the generators registered once as a resident
+    # set (bzamd_generators_*).  Never used for `value`.
     resident_ms = None
     resident_output = None
-    if world == 1:
-        handle = lib.bzamd_generators_new_device(curve_id, vp(generators), n, stream)
-        out2 = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
-        clock2 = StageClock(lib, stage_steps)
-        for _ in range(stage_steps):
-            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
-        torch.cuda.synchronize()
-        resident_stages, _ = clock2.collect(stage_steps)
-        for _ in range(max(args.warmup, 2)):
-            lib.bzamd_pipeline_next()
-            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
-        lib.bzamd_pipeline_flush(stream)
-        torch.cuda.synchronize()
-        resident_steps = max(args.steps, 50)
-        clock2 = StageClock(lib, resident_steps, ACCUMULATE_ONLY)
-        t1 = time.perf_counter()
-        for _ in range(resident_steps):
-            lib.bzamd_pipeline_next()
-            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
-        lib.bzamd_pipeline_flush(stream)
-        torch.cuda.synchronize()
-        resident_ms = 1e3 * (time.perf_counter() - t1) / resident_steps
-        resident_acc, _ = clock2.collect(resident_steps)
-        resident_stages["accumulate"] = resident_acc["accumulate"]
-        resident_output = out2.cpu().numpy().copy()
+    handle = lib.bzamd_generators_new_device(curve_id, vp(generators), n, stream)
+    out2 = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+    clock2 = StageClock(lib, stage_steps)
+    for _ in range(stage_steps):
+        lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+    torch.cuda.synchronize()
+    resident_stages, _ = clock2.collect(stage_steps)
+    for _ in range(max(args.warmup, 2)):
+        lib.bzamd_pipeline_next()
+        lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+    lib.bzamd_pipeline_flush(stream)
+    torch.cuda.synchronize()
+    resident_steps = max(args.steps, 50)
+    clock2 = StageClock(lib, resident_steps, ACCUMULATE_ONLY)
+    t1 = time.perf_counter()
+    for _ in range(resident_steps):
+        lib.bzamd_pipeline_next()
+        lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+    lib.bzamd_pipeline_flush(stream)
+    torch.cuda.synchronize()
+    resident_ms = 1e3 * (time.perf_counter() - t1) / resident_steps
+    resident_acc, _ = clock2.collect(resident_steps)
+    resident_stages["accumulate"] = resident_acc["accumulate"]
+    resident_output = out2.cpu().numpy().copy()
 
     for k in range(args.warmup):
         step(k)
@@ -646,8 +645,7 @@ def main():
     assert np.array_equal(lone_output, timed_output), "lone call disagrees with the sequence"
     assert resident_output is None or np.array_equal(resident_output, timed_output), \
         "resident path disagrees"
-    if world == 1:
-        lib.bzamd_generators_free(handle)  # (a hipFree: after the timed region)
+    lib.bzamd_generators_free(handle)  # (a hipFree: after the timed region)
     dist_info = None
     if world > 1:
         everyone = gathered.cpu().numpy().reshape(world, max_steps, 32)[:, :args.steps]
@@ -732,7 +730,7 @@ def main():
         }
         if verified:
             result["verified"] = verified
-        if resident_ms is not None:
+        if resident_ms is not None and world == 1:
             # the same column against a generator set registered once (bzamd_generators_*): Z = 1
             # addends and, for sets of 2^14 generators or more, window tables (2^(16 w) g_i
             # resident: one bucket set for all windows, no Horner chain)
