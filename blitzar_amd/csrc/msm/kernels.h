@@ -1198,51 +1198,11 @@ __device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end, u32 seg_log
 //     folds v_t = r_t + 8 suffix_t, and the one remaining multiple, block_first * (sum of the s_t),
 //     is formed by the first wavefront with the point spread over its lanes (curve/ed16_wave.h,
 //     ~10x less latency per dependent operation): ~28 % fewer additions per block.
-// Cross-lane sums of k_reduce without a workgroup-sized LDS array: inside a wavefront the lanes
-// exchange points with ds_bpermute shuffles (no allocation, no barrier), only the four wave totals
-// go through LDS.  The 256-entry tree of points this replaces cost 37-43 KiB of LDS per workgroup
-// and two barriers per level: 39 -> 3 KiB, a lone k_reduce 0.200 -> 0.197 ms at config 2.  (The
-// hope that the front of the next call, whose kernels want 40-76 KiB per workgroup, would run
-// faster beside a k_reduce that leaves them the LDS did not come true -- 1.00 ms per call in
-// sequence either way, and capping the kernel's registers at 168 / 128 to leave the register file
-// to others only adds spills: profiles/round3_ab_reduce_lds.log.)
-constexpr u32 kReduceWaves = kReduceThreads / 64;
-
-// sum of `v` over the workgroup, returned to thread 0 (`v` = identity for lanes with nothing)
-template <class C>
-__device__ __forceinline__ typename C::point
-block_sum(typename C::point v, typename C::point* wave_totals, u32 tid) {
-  for (u32 d = 32; d >= 1; d >>= 1) v = C::add(v, wave_shfl_down(v, d));
-  __syncthreads(); // wave_totals of an earlier use have been read
-  if ((tid & 63) == 0) wave_totals[tid >> 6] = v;
-  __syncthreads();
-  if (tid == 0) {
-    for (u32 w = 1; w < kReduceWaves; ++w) v = C::add(v, wave_totals[w]);
-  }
-  return v;
-}
-
-// inclusive suffix sums over the workgroup's lanes: lane t gets sum_{u >= t} x_u
-template <class C>
-__device__ __forceinline__ typename C::point
-block_suffix_scan(typename C::point x, typename C::point* wave_totals, u32 tid) {
-  const u32 lane = tid & 63, wave = tid >> 6;
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const typename C::point other = wave_shfl_down(x, d);
-    if (lane + d < 64) x = C::add(x, other);
-  }
-  __syncthreads();
-  if (lane == 0) wave_totals[wave] = x;
-  __syncthreads();
-  // the totals of the later waves, folded from the top (waves 0 .. 3: 3, 2, 1, 0 additions)
-  if (wave + 1 < kReduceWaves) {
-    typename C::point later = wave_totals[kReduceWaves - 1];
-    for (u32 w = kReduceWaves - 1; w-- > wave + 1;) later = C::add(later, wave_totals[w]);
-    x = C::add(x, later);
-  }
-  return x;
-}
-
+// (The tree below costs 37-43 KiB of LDS per workgroup.  Round 3 replaced it by wave shuffles --
+// 3 KiB, two barriers per level fewer, a lone k_reduce 0.200 -> 0.197 ms at config 2 -- hoping
+// the front of the next call would run faster beside it: it did not, and the 9-limb Weierstrass
+// curves went from 209 to 284 registers, one wavefront per SIMD instead of two, config 4's
+// k_reduce 33.0 -> 42.6 ms.  Reverted: profiles/round3_ab_reduce_lds.log.)
 template <class C>
 __global__ void __launch_bounds__(kReduceThreads)
     k_reduce(typename C::point* __restrict__ partials, u32 partial_stride,
@@ -1250,10 +1210,9 @@ __global__ void __launch_bounds__(kReduceThreads)
              const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
              const task_desc* __restrict__ tasks, u32 lane_log2) {
   using point = typename C::point;
-  __shared__ point wave_totals[kReduceWaves];
+  __shared__ point tree[kReduceThreads];
   // a latency chain at one wavefront per SIMD: when it runs beside another batch's k_accumulate
-  // (msm_context: throughput mode) its instructions go first, the accumulation fills the slots it
-  // leaves
+  // (msm_context::tail) its instructions go first, the accumulation fills the slots it leaves
   __builtin_amdgcn_s_setprio(BZ_REDUCE_PRIO);
   const task_desc task = tasks[blockIdx.y];
   const u32 nb = task.num_buckets;
@@ -1277,8 +1236,8 @@ __global__ void __launch_bounds__(kReduceThreads)
   // Heavy buckets first.  A bucket that holds a large share of a skewed column (constants,
   // booleans) spans thousands of segments and leaves one head partial per 64 of them: its owner
   // lane would add them one after the other (2^20 equal scalars: 512 dependent additions, 2 ms).
-  // The workgroup folds such buckets cooperatively -- the heads dealt out over the 256 lanes,
-  // block_sum on top -- and phase 1 picks the finished sums up from LDS.
+  // The workgroup folds such buckets cooperatively -- the heads dealt out over the 256 lanes, an
+  // LDS tree on top -- and phase 1 picks the finished sums up from LDS.
   __shared__ u32 heavy_bucket[kReduceMaxHeavy];
   __shared__ u32 heavy_count;
   __shared__ point heavy_sum[kReduceMaxHeavy];
@@ -1307,8 +1266,13 @@ __global__ void __launch_bounds__(kReduceThreads)
       part = any ? C::add(part, hd[list.index(j)]) : hd[list.index(j)];
       any = true;
     }
-    const point sum = block_sum<C>(part, wave_totals, tid);
-    if (tid == 0) heavy_sum[h] = C::add(sum, bs[b]);
+    tree[tid] = part;
+    __syncthreads();
+    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+      if (tid < stride && tid + stride < list.count) tree[tid] = C::add(tree[tid], tree[tid + stride]);
+      __syncthreads();
+    }
+    if (tid == 0) heavy_sum[h] = C::add(tree[0], bs[b]);
     __syncthreads();
   }
   point s = C::identity();
@@ -1338,24 +1302,31 @@ __global__ void __launch_bounds__(kReduceThreads)
   }
   if constexpr (C::has_wave_add_multiple) {
     // inclusive suffix scan of s over the 256 lanes
-    const point x = block_suffix_scan<C>(s, wave_totals, tid);
-    // v_t = r_t + 2^lane_log2 * suffix_t (t >= 1), summed over the workgroup
+    point x = s;
+    for (u32 d = 1; d < kReduceThreads; d <<= 1) {
+      tree[tid] = x;
+      __syncthreads();
+      if (tid + d < kReduceThreads) x = C::add(x, tree[tid + d]);
+      __syncthreads();
+    }
+    // v_t = r_t + 2^lane_log2 * suffix_t (t >= 1), folded by the tree
     if (tid != 0) r = C::add(r, C::dbl_n(x, static_cast<int>(lane_log2)));
-    const point sum = block_sum<C>(r, wave_totals, tid);
+    tree[tid] = r;
+    __syncthreads();
+    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+      if (tid < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
+      __syncthreads();
+    }
     // block offset: lane 0 holds suffix_0 = the sum of the block's buckets
     if (block_first == 0) {
-      if (tid == 0) *dst = sum;
+      if (tid == 0) *dst = tree[0];
       return;
     }
-    __shared__ point offset_operands[2];
-    if (tid == 0) {
-      offset_operands[0] = sum;
-      offset_operands[1] = x;
-    }
+    if (tid == 0) tree[1] = x;
     __syncthreads();
     if (tid < 64) {
-      const point out = C::wave_add_multiple(offset_operands[0], offset_operands[1], block_first);
-      if (tid == 0) *dst = out;
+      const point sum = C::wave_add_multiple(tree[0], tree[1], block_first);
+      if (tid == 0) *dst = sum;
     }
   } else {
     // r = sum (b - seg_first + 1) B_b ; add seg_first * s
@@ -1372,8 +1343,13 @@ __global__ void __launch_bounds__(kReduceThreads)
       }
       contrib = C::add(contrib, m);
     }
-    const point sum = block_sum<C>(contrib, wave_totals, tid);
-    if (tid == 0) *dst = sum;
+    tree[tid] = contrib;
+    __syncthreads();
+    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+      if (tid < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
+      __syncthreads();
+    }
+    if (tid == 0) *dst = tree[0];
   }
 }
 
