@@ -10,35 +10,19 @@
 
 namespace bz {
 
+// (Every array below is indexed with compile-time constants only: a run-time index into a small
+// register array makes hipcc park it in LDS or scratch -- the first version of this walker kept a
+// bit cursor into w[] and cost k_recode a dozen LDS round trips per digit.)
 struct digit_recoder {
-  u64 w[4];
+  u64 w[4]; // what is left of |x|: the next digit is its low c bits
   u32 c;
   u32 half;
   u32 carry;
-  u32 bit;
   bool negative;
 
-  // little-endian bit field [bit_offset, bit_offset + bit_width) of the row at `p`
-  BZ_HD void load(const u8* __restrict__ p, u32 bit_offset, u32 bit_width) {
-    w[0] = w[1] = w[2] = w[3] = 0;
-    p += bit_offset >> 3;
-    const u32 sh = bit_offset & 7;
-    if (sh == 0 && bit_width == 256 && (reinterpret_cast<uintptr_t>(p) & 7) == 0) {
-      const u64* q = reinterpret_cast<const u64*>(p);
-      w[0] = q[0];
-      w[1] = q[1];
-      w[2] = q[2];
-      w[3] = q[3];
-      return;
-    }
-    const u32 nbytes = (sh + bit_width + 7) >> 3; // <= 33
-    u64 t[5] = {0, 0, 0, 0, 0};
-    for (u32 i = 0; i < nbytes; ++i) {
-      t[i >> 3] |= static_cast<u64>(p[i]) << (8 * (i & 7));
-    }
-    if (sh != 0) {
-      for (int i = 0; i < 4; ++i) t[i] = (t[i] >> sh) | (t[i + 1] << (64 - sh));
-    }
+  // keep bits [0, bit_width) of the 256-bit value t[0..3]
+  BZ_HD void keep_field(const u64 t[4], u32 bit_width) {
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u32 lo = 64 * i;
       if (bit_width <= lo) {
@@ -51,24 +35,42 @@ struct digit_recoder {
     }
   }
 
+  // little-endian bit field [bit_offset, bit_offset + bit_width) of the row at `p`
+  BZ_HD void load(const u8* __restrict__ p, u32 bit_offset, u32 bit_width) {
+    p += bit_offset >> 3;
+    const u32 sh = bit_offset & 7;
+    if (sh == 0 && bit_width == 256 && (reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+      const u64* q = reinterpret_cast<const u64*>(p);
+      w[0] = q[0];
+      w[1] = q[1];
+      w[2] = q[2];
+      w[3] = q[3];
+      return;
+    }
+    const u32 nbytes = (sh + bit_width + 7) >> 3; // <= 33
+    u64 t[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (u32 i = 0; i < 33; ++i) {
+      if (i < nbytes) t[i >> 3] |= static_cast<u64>(p[i]) << (8 * (i & 7));
+    }
+    if (sh != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = (t[i] >> sh) | (t[i + 1] << (64 - sh));
+    }
+    keep_field(t, bit_width);
+  }
+
   // the same field given as ten aligned 32-bit words and the bit position (< 40) of the field's
   // first bit inside them (k_recode_packed reads its LDS tile this way: no byte loads)
   BZ_HD void load_words32(const u32* __restrict__ d, u32 bit_shift, u32 bit_width) {
     u64 t[5];
+#pragma unroll
     for (int i = 0; i < 5; ++i) t[i] = d[2 * i] | (static_cast<u64>(d[2 * i + 1]) << 32);
     if (bit_shift != 0) {
+#pragma unroll
       for (int i = 0; i < 4; ++i) t[i] = (t[i] >> bit_shift) | (t[i + 1] << (64 - bit_shift));
     }
-    for (int i = 0; i < 4; ++i) {
-      const u32 lo = 64 * i;
-      if (bit_width <= lo) {
-        w[i] = 0;
-      } else if (bit_width < lo + 64) {
-        w[i] = t[i] & ((u64{1} << (bit_width - lo)) - 1);
-      } else {
-        w[i] = t[i];
-      }
-    }
+    keep_field(t, bit_width);
   }
 
   BZ_HD void init(const u8* __restrict__ p, u32 bit_offset, u32 bit_width, bool is_signed,
@@ -88,42 +90,36 @@ struct digit_recoder {
     c = window_bits;
     half = 1u << (c - 1);
     carry = 0;
-    bit = 0;
     negative = false;
     if (is_signed) {
       const u32 nbits = bit_width;
       const u32 top = nbits - 1;
-      negative = ((w[top >> 6] >> (top & 63)) & 1) != 0;
+      const u32 word = top >> 6;
+      const u64 top_word = word == 0 ? w[0] : (word == 1 ? w[1] : (word == 2 ? w[2] : w[3]));
+      negative = ((top_word >> (top & 63)) & 1) != 0;
       if (negative) {
         // |x| = 2^nbits - x, computed over the nbits-wide field
+        u64 t[4];
         u64 cin = 1;
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
           const u64 v = ~w[i] + cin;
           cin = (cin != 0 && v == 0) ? 1 : 0;
-          w[i] = v;
+          t[i] = v;
         }
-        for (int i = 0; i < 4; ++i) {
-          const u32 lo = 64 * i;
-          if (nbits <= lo) {
-            w[i] = 0;
-          } else if (nbits < lo + 64) {
-            w[i] &= (u64{1} << (nbits - lo)) - 1;
-          }
-        }
+        keep_field(t, nbits);
       }
     }
   }
 
-  // next signed digit, least-significant window first, column sign already applied
+  // next signed digit, least-significant window first, column sign already applied.  The value
+  // is shifted down by c afterwards (c in 1..16, so 64 - c is a valid shift count).
   BZ_HD int next() {
-    u32 u = 0;
-    if (bit < 256) {
-      const u32 word = bit >> 6, sh = bit & 63;
-      u64 v = w[word] >> sh;
-      if (sh + c > 64 && word + 1 < 4) v |= w[word + 1] << (64 - sh);
-      u = static_cast<u32>(v) & ((1u << c) - 1);
-    }
-    bit += c;
+    const u32 u = static_cast<u32>(w[0]) & ((1u << c) - 1);
+    w[0] = (w[0] >> c) | (w[1] << (64 - c));
+    w[1] = (w[1] >> c) | (w[2] << (64 - c));
+    w[2] = (w[2] >> c) | (w[3] << (64 - c));
+    w[3] >>= c;
     const u32 t = u + carry;
     int d;
     if (t > half) {
