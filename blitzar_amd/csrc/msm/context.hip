@@ -60,18 +60,12 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_OVERLAP_TAILS", ctx->overlap_tails);
   flag("BLITZAR_AMD_OVERLAP_FRONT", ctx->overlap_front);
   flag("BLITZAR_AMD_FRONT_PRIORITY", ctx->front_high_priority);
-  flag("BLITZAR_AMD_ACC_MASKED", ctx->acc_masked);
   flag("BLITZAR_AMD_DEDICATED_QUEUES", ctx->dedicated_queues);
   flag("BLITZAR_AMD_FAST_RECODE", ctx->fast_recode);
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");
     ctx->two_tail_streams = streams == 2;
-  }
-  if (const char* v = std::getenv("BLITZAR_AMD_FRONT_WAVES")) {
-    const unsigned long waves = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(waves <= 8, "BLITZAR_AMD_FRONT_WAVES must be in [0, 8]");
-    ctx->front_waves = static_cast<u32>(waves);
   }
   if (const char* v = std::getenv("BLITZAR_AMD_FRONT_CUS")) {
     const unsigned long cus = std::strtoul(v, nullptr, 10);

@@ -178,23 +178,6 @@ struct msm_context {
   bool two_tail_streams = true; // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
   u32 front_cus = 0;          // BLITZAR_AMD_FRONT_CUS: CUs reserved for the front stream (0: no masks)
   bool front_high_priority = true; // BLITZAR_AMD_FRONT_PRIORITY=0: the front's queue at normal priority
-  bool acc_masked = true;     // BLITZAR_AMD_ACC_MASKED=0: the accumulation may also use the front's CUs
-  // Without masks the front's kernels share the CUs with the accumulation: their launches then ask
-  // for enough (unused) dynamic LDS that at most `front_waves` of their waves fit a SIMD -- the
-  // 1024-lane sort workgroups would otherwise take all 8 wave slots of every SIMD they land on and
-  // leave the accumulation, which is the stage that must not slow down, no room beside them
-  // (BLITZAR_AMD_FRONT_WAVES, 0: no cap).
-  u32 front_waves = 0;
-  size_t static_lds_recode = 0, static_lds_hist = 0, static_lds_scatter = 0, static_lds_sort = 0;
-  // extra dynamic LDS for a front launch of `threads`-lane workgroups that already use `have` bytes
-  size_t front_lds_pad(bool capped, u32 threads, size_t have) const {
-    if (!capped || front_waves == 0) return 0;
-    const u32 waves_per_simd = threads / 256 == 0 ? 1 : threads / 256;
-    const u32 allowed = front_waves / waves_per_simd == 0 ? 1 : front_waves / waves_per_simd;
-    // more than an (allowed + 1)-th of the CU's 160 KiB: `allowed` workgroups fit, one more does not
-    const size_t target = size_t{160} * 1024 / (allowed + 1) + 1024;
-    return have >= target ? 0 : target - have;
-  }
   // A stream with a hardware queue of its own.  The HIP runtime multiplexes the streams of a process
   // over a few hardware queues per priority level (4 by default), and packets of one queue execute
   // in order: an internal stream that lands on the queue of another one (a process with many
@@ -243,7 +226,6 @@ struct msm_context {
       const u32 split = static_cast<u32>(cus) - front_cus;
       for (u32 i = 0; i < static_cast<u32>(cus); ++i) {
         (i >= split ? fm : am)[i / 32] |= 1u << (i % 32);
-        if (!acc_masked) am[i / 32] |= 1u << (i % 32);
       }
       front = make_stream(&fm);
       acc = make_stream(&am);
@@ -331,15 +313,6 @@ static void configure_sort_kernels(msm_context& ctx) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  auto static_lds = [](const void* fn) {
-    hipFuncAttributes attr{};
-    BZ_HIP_CHECK(hipFuncGetAttributes(&attr, fn));
-    return static_cast<size_t>(attr.sharedSizeBytes);
-  };
-  ctx.static_lds_recode = static_lds(reinterpret_cast<const void*>(k_recode));
-  ctx.static_lds_hist = static_lds(reinterpret_cast<const void*>(k_group_hist));
-  ctx.static_lds_scatter = static_lds(reinterpret_cast<const void*>(k_group_scatter<true>));
-  ctx.static_lds_sort = static_lds(reinterpret_cast<const void*>(k_group_sort));
   ctx.kernels_configured = true;
 }
 
@@ -665,8 +638,6 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // call runs feeds its next stage.)
   wait_for(earlier(ctx.acc_done, 2), fs);
   wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
-  // sharing CUs with the accumulation (no masks): cap the front's waves per SIMD
-  const bool capped = mode.split && ctx.front_cus == 0;
   // caller generators -> addends.  (Dealing this kernel's workgroups into the group sort's launch --
   // the one HBM-saturating kernel of the front inside the LDS-bound one -- was built and measured in
   // round 3: sort + conversion 0.171 -> 0.183 ms, profiles/round3_ab_front_fusion.log; removed.)
@@ -698,21 +669,18 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     }
     const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
     if (rows32_c16 && ctx.fast_recode) {
-      hipLaunchKernelGGL(k_recode_rows32_c16, dim3(chunks, num_cols), dim3(256),
-                         ctx.front_lds_pad(capped, 256, 0), fs, b.digits, b.cols, b.tasks,
-                         b.group_cursor, zero_words);
+      hipLaunchKernelGGL(k_recode_rows32_c16, dim3(chunks, num_cols), dim3(256), 0, fs, b.digits,
+                         b.cols, b.tasks, b.group_cursor, zero_words);
       return;
     }
     const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
     const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
-    hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256),
-                       ctx.front_lds_pad(capped, 256, ctx.static_lds_recode), fs, b.digits, b.cols,
+    hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, fs, b.digits, b.cols,
                        b.tasks, num_cols, chunks, b.group_cursor, zero_words);
   });
   ctx.timer.timed(timing, 2, fs, [&] {
     hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       part_lds + ctx.front_lds_pad(capped, kSortThreads, ctx.static_lds_hist + part_lds),
-                       fs, b.group_cursor, b.big_tasks, b.digits, b.tasks);
+                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks);
     u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
     hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, fs, b.group_cursor,
                        b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
@@ -721,18 +689,15 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
       const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
       hipLaunchKernelGGL(k_group_scatter<true>, dim3(plan.max_task_slices, num_tasks),
-                         dim3(kSortThreads),
-                         staged_lds + ctx.front_lds_pad(capped, kSortThreads,
-                                                        ctx.static_lds_scatter + staged_lds),
-                         fs, b.records, b.group_cursor, b.digits, b.tasks);
+                         dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
+                         b.tasks);
     } else {
       hipLaunchKernelGGL(k_group_scatter<false>, dim3(plan.max_task_slices, num_tasks),
                          dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
     hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads),
-                       ctx.front_lds_pad(capped, kGroupSortThreads, ctx.static_lds_sort), fs,
-                       b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
+                       0, fs, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
                        b.group_chunk, b.tasks);
     // oversized groups (skewed digits); both launches find nothing to do on uniform data
     hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
