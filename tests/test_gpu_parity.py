@@ -698,13 +698,13 @@ def test_sequence_of_2_31_plus_5_rows(gpu_backend, oracle):
 
 @pytest.mark.parametrize("curve_id", [1, 2, 3])
 def test_mid_size_column_with_16_bit_windows(gpu_backend, oracle, curve_id):
-    """a 2^17-row column on ORACLE-made generators (1024 outputs of the reference's
+    """a 2^16-row column on ORACLE-made generators (1024 outputs of the reference's
     generate_random_element, then the chain g_i = g_{i-1} + g_0 built with the reference's curve
     code) with the window width pinned to 16: stored digit -32768, 2^15 buckets per window -- the
     regime of BASELINE configs 3-5, compared with the reference MSM itself"""
     api = gpu_backend
     lib = api.load()
-    n = 1 << 17
+    n = 1 << 16
     rng = np.random.default_rng(6100 + curve_id)
     gens = util.weierstrass_generators(curve_id, n, distinct_seeds=1024)
     col = rng.integers(0, 256, (n, 32), dtype=np.uint8)
