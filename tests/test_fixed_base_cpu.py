@@ -62,7 +62,7 @@ def test_plain_packed_vlen_match_oracle(cpu_backend, oracle, cid):
     h.close()
 
 
-@pytest.mark.parametrize("cid", [0, 2])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_outputs_wider_than_256_bits(cpu_backend, oracle, cid):
     """the reference takes any unsigned bit width per output (cbindings/blitzar_api.h:712,
     pippenger2/multiexponentiation.h:207-288: one bit plane per bit); here such an output is
