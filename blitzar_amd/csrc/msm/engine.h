@@ -241,6 +241,18 @@ struct msm_context {
     acc = make_stream();
   }
   bool any_pending() const { return joined < seq; }
+  // End of pipelined batch k: the caller's stream picks up the batch TWO before it (whose buffers
+  // batch k reused, so it is long done): a pipelined result is complete on the stream once two
+  // further calls have been enqueued, or after a flush.  (Waiting for the previous batch here
+  // would put its k_horner in front of whatever the caller enqueues next -- in the overlap_front
+  // arrangement: in front of the next call's entry mark, i.e. of the next front.)
+  void join_two_back(hipStream_t stream, u64 k) {
+    if (k >= 2 && (joined < k - 1 || stream != joined_on)) {
+      horner_done[(k - 2) & 3].wait(stream);
+      joined = k - 1;
+      joined_on = stream;
+    }
+  }
   // make `stream` wait for every pipelined batch enqueued so far (k_horner runs on ONE stream, in
   // order, and is the last stage of a batch: the last batch's mark covers everything)
   void join_all(hipStream_t stream) {
@@ -579,6 +591,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       ctx.horner_done[k & 3].record(hs);
       ctx.pipe_layout = layout;
       ctx.seq = k + 1;
+      ctx.join_two_back(stream, k);
     }
     return;
   }
@@ -741,17 +754,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     ctx.horner_done[k & 3].record(hs);
     ctx.pipe_layout = layout;
     ctx.seq = k + 1;
-    // The caller's stream picks up the batch TWO before this one (whose buffers this batch reused,
-    // so it is long done): a pipelined call's result is complete on the stream once two further
-    // calls have been enqueued, or after a flush.  (Waiting for the previous batch here would put
-    // its horner in front of the next call's entry mark, i.e. of the next front: the front of
-    // batch k + 1 could not start until the tails of batch k - 1 are through, most of the way into
-    // accumulation k, which is what it is meant to run beside.)
-    if (k >= 2 && (ctx.joined < k - 1 || stream != ctx.joined_on)) {
-      ctx.horner_done[(k - 2) & 3].wait(stream);
-      ctx.joined = k - 1;
-      ctx.joined_on = stream;
-    }
+    ctx.join_two_back(stream, k);
   }
   if (timing) ctx.timer.calls += 1;
   g_kernel_launches += 10;

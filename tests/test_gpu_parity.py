@@ -476,6 +476,35 @@ def _pipelined_calls(api, lib, oracle, dev, ctypes, torch):
     torch.cuda.synchronize()
     for j, out in results:
         assert np.array_equal(out.cpu().numpy(), jobs[j][4]), "operands overwritten behind a call"
+    # calls whose columns are all empty keep their place in a sequence (identities, no tasks), and
+    # the two-calls rule holds across them; a flush from ANOTHER stream completes everything there
+    empty = (api.sxt_sequence_descriptor * 2)()
+    empty[0] = api.sxt_sequence_descriptor(32, 0, None, 0)
+    empty[1] = api.sxt_sequence_descriptor(4, 0, None, 1)
+    identity = oracle.commit(0, [(np.zeros((0, 32), np.uint8), False)] * 2,
+                             oracle.ristretto_generators(1))
+    curve_id, d_gens, _, desc, want = jobs[0]
+    seq = []
+    for i in range(6):
+        lib.bzamd_pipeline_next()
+        if i % 2 == 0:
+            out = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+            lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 1, desc,
+                                 ctypes.c_void_p(d_gens.data_ptr()), stream)
+            seq.append((want, out))
+        else:
+            out = torch.ones((2, 32), dtype=torch.uint8, device=dev)
+            lib.bzamd_msm_device(curve_id, ctypes.c_void_p(out.data_ptr()), 2, empty,
+                                 ctypes.c_void_p(d_gens.data_ptr()), stream)
+            seq.append((identity, out))
+    other = torch.cuda.Stream(device=dev)
+    lib.bzamd_pipeline_flush(ctypes.c_void_p(other.cuda_stream))
+    with torch.cuda.stream(other):
+        snaps = [(w, o.clone()) for w, o in seq]
+    other.synchronize()
+    for w, got in snaps:
+        assert np.array_equal(got.cpu().numpy(), w), "empty calls inside a pipelined sequence"
+    torch.cuda.synchronize()
     # a plain call after a pipelined one needs no flush of its own
     curve_id, d_gens, _, desc, want = jobs[0]
     h = lib.bzamd_generators_new_device(curve_id, ctypes.c_void_p(d_gens.data_ptr()), 40000, stream)
