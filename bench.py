@@ -569,52 +569,63 @@ def main():
         if world > 1:
             coll.all_gather(gathered, outs)
 
-    # untimed legs first (they used to follow the timed region; ahead of it the GPU enters the W
-    # warmup steps and the K timed steps at its sustained clocks, as in a service under load -- the
-    # first ~50 ms after an idle period run ~8 % slower): the six stage times and the latency of a
-    # lone call with plain stream semantics (no throughput mode), then the resident-generators leg
+    # Untimed legs: the six stage times and the latency of a lone call with plain stream semantics (no
+    # throughput mode), and the resident-generators leg (every rank runs it, rank 0 of a single-GPU
+    # run reports it: the same step with the generators registered once as a resident set,
+    # bzamd_generators_*; never used for `value`).
     stage_steps = min(args.steps, 50)
-    clock = StageClock(lib, stage_steps)
-    for _ in range(stage_steps):
-        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
-    torch.cuda.synchronize()
-    per_call, _ = clock.collect(stage_steps)
-    t_single = time.perf_counter()
-    for _ in range(stage_steps):
-        lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
-    torch.cuda.synchronize()
-    single_call_ms = 1e3 * (time.perf_counter() - t_single) / stage_steps
+    legs = {}
 
-    lone_output = out.cpu().numpy().copy()
-    # informational second leg (every rank runs it, rank 0 of a single-GPU run reports it), also
-    # ahead of the timed region: the same step with the generators registered once as a resident
-    # set (bzamd_generators_*).  Never used for `value`.
-    resident_ms = None
-    resident_output = None
+    def lone_passes():
+        clock = StageClock(lib, stage_steps)
+        for _ in range(stage_steps):
+            lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
+        torch.cuda.synchronize()
+        legs["per_call"], _ = clock.collect(stage_steps)
+        t_single = time.perf_counter()
+        for _ in range(stage_steps):
+            lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream)
+        torch.cuda.synchronize()
+        legs["single_call_ms"] = 1e3 * (time.perf_counter() - t_single) / stage_steps
+        legs["lone_output"] = out.cpu().numpy().copy()
+
     handle = lib.bzamd_generators_new_device(curve_id, vp(generators), n, stream)
     out2 = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
-    clock2 = StageClock(lib, stage_steps)
-    for _ in range(stage_steps):
-        lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
-    torch.cuda.synchronize()
-    resident_stages, _ = clock2.collect(stage_steps)
-    for _ in range(max(args.warmup, 2)):
-        lib.bzamd_pipeline_next()
-        lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
-    lib.bzamd_pipeline_flush(stream)
-    torch.cuda.synchronize()
-    resident_steps = max(args.steps, 50)
-    clock2 = StageClock(lib, resident_steps, ACCUMULATE_ONLY)
-    t1 = time.perf_counter()
-    for _ in range(resident_steps):
-        lib.bzamd_pipeline_next()
-        lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
-    lib.bzamd_pipeline_flush(stream)
-    torch.cuda.synchronize()
-    resident_ms = 1e3 * (time.perf_counter() - t1) / resident_steps
-    resident_acc, _ = clock2.collect(resident_steps)
-    resident_stages["accumulate"] = resident_acc["accumulate"]
-    resident_output = out2.cpu().numpy().copy()
+
+    def resident_lone_pass():
+        clock2 = StageClock(lib, stage_steps)
+        for _ in range(stage_steps):
+            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+        torch.cuda.synchronize()
+        legs["resident_stages"], _ = clock2.collect(stage_steps)
+
+    def resident_sequence():
+        for _ in range(max(args.warmup, 2)):
+            lib.bzamd_pipeline_next()
+            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+        lib.bzamd_pipeline_flush(stream)
+        torch.cuda.synchronize()
+        resident_steps = max(args.steps, 50)
+        clock2 = StageClock(lib, resident_steps, ACCUMULATE_ONLY)
+        t1 = time.perf_counter()
+        for _ in range(resident_steps):
+            lib.bzamd_pipeline_next()
+            lib.bzamd_msm_device_resident(vp(out2), 1, desc, handle, stream)
+        lib.bzamd_pipeline_flush(stream)
+        torch.cuda.synchronize()
+        legs["resident_ms"] = 1e3 * (time.perf_counter() - t1) / resident_steps
+        legs["resident_acc"], _ = clock2.collect(resident_steps)
+        legs["resident_output"] = out2.cpu().numpy().copy()
+
+    # Order.  The device idles at ~100 MHz and a 20-step timed region is 20 ms long: entered from an
+    # idle or lightly loaded device it runs ~8 % slower than the same steps in a long sequence, and
+    # entered after several hundred ms of full load it runs slower again (a 200-call sequence ahead
+    # of it: 1.04-1.06 ms per step against 1.01-1.02 after 50 calls, tools/pipeline_bench).  So the
+    # one leg that is a sequence of >= 50 calls in throughput mode runs right before the W warmup
+    # steps, and the lone-call legs (low load: 40 % of a lone call is tails) after the timed region.
+    # (Measured, three runs each on one box: every leg ahead of the timed region 1.10 / 1.10 / 1.06
+    # ms per step, this order 1.054 / 1.044 / 1.048.)
+    resident_sequence()
 
     for k in range(args.warmup):
         step(k)
@@ -641,10 +652,14 @@ def main():
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
+    lone_passes()
+    resident_lone_pass()
+    per_call, single_call_ms, lone_output = legs["per_call"], legs["single_call_ms"], legs["lone_output"]
+    resident_ms, resident_stages = legs["resident_ms"], legs["resident_stages"]
+    resident_stages["accumulate"] = legs["resident_acc"]["accumulate"]
     per_call["accumulate"] = timed_stages["accumulate"]
     assert np.array_equal(lone_output, timed_output), "lone call disagrees with the sequence"
-    assert resident_output is None or np.array_equal(resident_output, timed_output), \
-        "resident path disagrees"
+    assert np.array_equal(legs["resident_output"], timed_output), "resident path disagrees"
     lib.bzamd_generators_free(handle)  # (a hipFree: after the timed region)
     dist_info = None
     if world > 1:
