@@ -92,7 +92,7 @@ void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_ta
 // tests: every column takes this window width where it can (0 = the cost model chooses)
 void msm_context_set_window_bits(msm_context* ctx, u32 window_bits);
 // throughput mode (bzamd_msm_device_pipelined): the next MSM enqueued on this context leaves its last
-// stage running on the context's tail stream; `join_tail` makes `stream` wait for it
+// stages running on the context's own streams; `join_tail` makes `stream` wait for everything pending
 void msm_context_defer_next_tail(msm_context* ctx);
 void msm_context_join_tail(msm_context* ctx, hipStream_t stream);
 // sorted entries per k_accumulate lane = 2^a (3..10), buckets per k_reduce lane = 2^r (1..8);

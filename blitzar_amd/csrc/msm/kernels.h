@@ -1212,7 +1212,7 @@ __global__ void __launch_bounds__(kReduceThreads)
   using point = typename C::point;
   __shared__ point tree[kReduceThreads];
   // a latency chain at one wavefront per SIMD: when it runs beside another batch's k_accumulate
-  // (msm_context::tail) its instructions go first, the accumulation fills the slots it leaves
+  // (msm_context: throughput mode) its instructions go first, the accumulation fills the slots it leaves
   __builtin_amdgcn_s_setprio(BZ_REDUCE_PRIO);
   const task_desc task = tasks[blockIdx.y];
   const u32 nb = task.num_buckets;

@@ -165,7 +165,7 @@ struct msm_tuning {
   u32 force_window_bits = 0;         // tests (bzamd_set_window_bits): this width wherever a column allows it
   u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
   u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
-  // throughput mode (engine.h, msm_context::tail): calls with this many columns or more ignore
+  // throughput mode (engine.h, msm_context): calls with this many columns or more ignore
   // bzamd_pipeline_next (BLITZAR_AMD_DEFER_COLUMNS).  Measured on MI355X, curve25519, k columns x 2^20
   // rows, ms per call lone / in sequence (tools/multi_column_bench.py): 2: 2.41 / 2.03, 4: 4.19 / 3.73,
   // 8: 7.60 / 7.13, 16: 14.46 / 13.93, 32: 27.73 / 27.22; with 256 columns (bn254) the fork and the
