@@ -165,6 +165,10 @@ struct msm_context {
   // BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.  A lone call never forks (every
   // fork / join pair costs ~25 us of stream bubbles).
   hipStream_t front = nullptr, acc = nullptr, tail = nullptr, tail2 = nullptr;
+  // the tail streams for callers on the NULL stream: plain non-blocking ones (a CU-masked stream is
+  // a blocking stream -- every operation the caller puts on the NULL stream would wait for it, and
+  // the tails it is meant to run beside: 2 columns x 2^20 rows 2.03 -> 2.40 ms per call)
+  hipStream_t tail_plain = nullptr, tail2_plain = nullptr;
   bool pipe_streams_made = false;
   stage_mark entry;
   stage_mark front_done[4], acc_done[4], reduce_done[4], horner_done[4];
@@ -184,7 +188,7 @@ struct msm_context {
   // streams: PyTorch creates 32 at its first side stream) inherits that stream's waits, and the
   // stages the mode is meant to overlap serialise again (measured: 1.12 -> 1.48 ms per step under
   // torch).  A stream created with a CU mask -- here the mask of ALL CUs -- always gets a queue of its
-  // own.  (Such streams are blocking streams: work on the NULL stream synchronises with them.)
+  // own.  (Such streams are blocking streams: callers on the NULL stream get plain ones, below.)
   bool dedicated_queues = true; // BLITZAR_AMD_DEDICATED_QUEUES=0: plain non-blocking streams
   bool fast_recode = true;      // BLITZAR_AMD_FAST_RECODE=0: the generic recode kernel for every shape
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
@@ -208,11 +212,19 @@ struct msm_context {
     BZ_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
-  void make_pipe_streams() {
-    if (pipe_streams_made) return;
+  void make_pipe_streams(bool null_caller) {
+    // (each kind only when a caller of that kind shows up: an idle blocking stream still costs
+    // every NULL-stream launch a cross-queue dependency -- 1.00 -> 1.19 ms per call)
+    if (null_caller && tail_plain == nullptr) {
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail_plain, hipStreamNonBlocking));
+      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail2_plain, hipStreamNonBlocking));
+    }
+    if (!null_caller && tail == nullptr) {
+      tail = make_stream();
+      tail2 = make_stream();
+    }
+    if (pipe_streams_made || null_caller) return;
     pipe_streams_made = true;
-    tail = make_stream();
-    tail2 = make_stream();
     if (!overlap_front) return;
     int device = 0, cus = 0;
     BZ_HIP_CHECK(hipGetDevice(&device));
@@ -286,7 +298,7 @@ struct msm_context {
       reduce_done[i].destroy();
       horner_done[i].destroy();
     }
-    for (hipStream_t s : {front, acc, tail2, tail}) {
+    for (hipStream_t s : {front, acc, tail2, tail, tail2_plain, tail_plain}) {
       if (s != nullptr) (void)hipStreamDestroy(s);
     }
   }
@@ -395,7 +407,8 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   for (const auto& c : cols) nonempty_columns += c.n != 0 ? 1 : 0;
   pipe_mode mode;
   mode.piped = ctx.defer_tail && ctx.overlap_tails && nonempty_columns < ctx.tuning.defer_max_columns;
-  mode.split = mode.piped && ctx.overlap_front;
+  // (the front / accumulation streams of overlap_front are blocking streams: not for the NULL stream)
+  mode.split = mode.piped && ctx.overlap_front && stream != nullptr;
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   bool any_signed = false;
@@ -452,7 +465,7 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     batches.push_back(std::move(plan));
     begin = end;
   }
-  if (mode.piped) ctx.make_pipe_streams();
+  if (mode.piped) ctx.make_pipe_streams(stream == nullptr);
   // a call outside the mode uses buffer set 0 on the caller's stream: everything pending first
   if (!mode.piped) ctx.join_all(stream);
   // one allocation sized for the largest batch: later resets never reallocate (no mid-call sync)
@@ -534,7 +547,9 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                 static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
                 static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
                 static_cast<u64>(d_addends == nullptr),
-                static_cast<u64>(mode.piped) | static_cast<u64>(mode.split) << 1}) {
+                static_cast<u64>(mode.piped) | static_cast<u64>(mode.split) << 1 |
+                    // (the NULL stream's callers use tail streams of their own: a change joins first)
+                    static_cast<u64>(stream == nullptr) << 2}) {
     layout = (layout ^ v) * 0x100000001b3ull;
   }
   if (ctx.any_pending() && layout != ctx.pipe_layout) {
@@ -547,8 +562,10 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   const u32 end_set = mode.piped ? static_cast<u32>(k % mode.end_sets()) : 0;
   hipStream_t fs = mode.split ? ctx.front : stream;
   hipStream_t as = mode.split ? ctx.acc : stream;
-  hipStream_t rs = mode.piped ? ctx.tail : stream;
-  hipStream_t hs = mode.piped ? (ctx.two_tail_streams ? ctx.tail2 : ctx.tail) : stream;
+  const bool null_caller = stream == nullptr;
+  hipStream_t rs = mode.piped ? (null_caller ? ctx.tail_plain : ctx.tail) : stream;
+  hipStream_t hs = !mode.piped ? stream
+                   : (ctx.two_tail_streams ? (null_caller ? ctx.tail2_plain : ctx.tail2) : rs);
   // completion marks of earlier batches (none outside the mode: join_all came first)
   auto earlier = [&](stage_mark* ring, u64 back) -> const stage_mark* {
     return mode.piped && k >= back ? &ring[(k - back) & 3] : nullptr;

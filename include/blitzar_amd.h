@@ -105,9 +105,9 @@ uint64_t bzamd_stage_timing_collect(double* out_ms);
  * the call returns).  The commitments of such a call are complete on `stream` only once TWO later
  * such calls on the device have been enqueued on it, or after bzamd_pipeline_flush(stream): do not
  * read them earlier.  Calls with 64 or more columns ignore the request (their tails fill the
- * machine).  A pipelined sequence lives on ONE stream and one caller thread per device.  Pass a
- * stream of your own (hipStreamNonBlocking): every operation on the NULL stream implicitly waits for
- * the engine's internal streams and serialises the stages again (still correct, no overlap).
+ * machine).  A pipelined sequence lives on ONE stream and one caller thread per device (the NULL
+ * stream or a stream of the caller's own: the engine picks internal streams that do not
+ * synchronise with it implicitly; changing between the two inside a sequence joins it first).
  * (Measured on MI355X, 2^20 curve25519 rows: see DESIGN.md section 9.) */
 void bzamd_pipeline_next(void);
 void bzamd_pipeline_flush(void* stream);
