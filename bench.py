@@ -533,9 +533,8 @@ def main():
 
     lib = api.load()
     assert api.init(api.SXT_GPU_BACKEND, 0) == 0
-    # a stream of the bench's own, not the NULL stream: the engine's throughput mode runs the stages
-    # of consecutive calls on internal streams, and every operation on the NULL stream implicitly
-    # waits for all blocking streams of the process (include/blitzar_amd.h, bzamd_pipeline_next)
+    # a stream of the bench's own (callers on the NULL stream work too, the engine then uses plain
+    # non-blocking tail streams: include/blitzar_amd.h, bzamd_pipeline_next)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     oracle = None if args.no_cpu_baseline else load_oracle()
@@ -617,15 +616,39 @@ def main():
         legs["resident_acc"], _ = clock2.collect(resident_steps)
         legs["resident_output"] = out2.cpu().numpy().copy()
 
-    # Order.  The device idles at ~100 MHz and a 20-step timed region is 20 ms long: entered from an
-    # idle or lightly loaded device it runs ~8 % slower than the same steps in a long sequence, and
-    # entered after several hundred ms of full load it runs slower again (a 200-call sequence ahead
-    # of it: 1.04-1.06 ms per step against 1.01-1.02 after 50 calls, tools/pipeline_bench).  So the
-    # one leg that is a sequence of >= 50 calls in throughput mode runs right before the W warmup
-    # steps, and the lone-call legs (low load: 40 % of a lone call is tails) after the timed region.
-    # (Measured, three runs each on one box: every leg ahead of the timed region 1.10 / 1.10 / 1.06
-    # ms per step, this order 1.054 / 1.044 / 1.048.)
+    def long_sequence():
+        # the timed region's own step, >= 50 times in one sequence: the sustained rate, reported
+        # beside the K-step figure (`sustained_ms_per_step`); its first calls size the workspace
+        # of this call shape (hipMalloc: tens of ms of idle device)
+        for k in range(2):
+            step(0)
+        finish()
+        torch.cuda.synchronize()
+        # one sequence; the clock (two events on the caller's stream) starts behind its 30th call:
+        # the device comes out of the allocation gap above at reduced clocks
+        calls = max(args.steps, 50)
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(30 + calls):
+            if k == 30:
+                begin.record()
+            step(k % max_steps)
+        finish()
+        end.record()
+        torch.cuda.synchronize()
+        legs["sustained_ms"] = begin.elapsed_time(end) / calls
+        legs["sustained_calls"] = calls
+
+    # Order.  The device idles at ~100 MHz and comes back slowly: after ANY idle gap (20 ms are
+    # enough) the first calls of a sequence take 1.14, 1.11, 1.06, 1.03, 1.00, 0.98 ms ... and the
+    # sustained 0.96 only after ~30 ms of load (tools/prof/clock_course.py; sustained means
+    # sustained: 3000 calls in sequence stay at 0.963).  A 20-step timed region is 20 ms long, so
+    # entered from an idle or lightly loaded device it measures the ramp, not the engine.  Hence:
+    # the legs that are long sequences in throughput mode run right before the W warmup steps --
+    # the last of them with the timed region's own call shape, so that nothing is allocated between
+    # it and the clock -- and the lone-call legs (low load: 40 % of a lone call is tails) after the
+    # timed region.
     resident_sequence()
+    long_sequence()
 
     for k in range(args.warmup):
         step(k)
@@ -728,10 +751,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "single_call_ms": single_call_ms,
+            "sustained_ms_per_step": legs["sustained_ms"],
+            "sustained_steps": legs["sustained_calls"],
             "mode": "throughput mode of the library (bzamd_pipeline_next / bzamd_pipeline_flush): the "
                     "last stage of step k (one workgroup per column) runs beside the front of step "
                     "k + 1; all K commitments are complete, and the last one verified, inside the "
-                    "timed region; `single_call_ms` = a lone call with plain stream semantics",
+                    "timed region; `single_call_ms` = a lone call with plain stream semantics; "
+                    "`sustained_ms_per_step` = the same step over the last `sustained_steps` calls "
+                    "of a longer sequence that runs right before the warmup steps (two events on "
+                    "the caller's stream, flush included)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -63,10 +63,10 @@ template <class P> struct sw29 {
   struct pm {
     fe plus, minus;
   };
-  BZ_HD static pm plus_minus(const fe& t1, const fe& u) {
+  template <int K = 8> BZ_HD static pm plus_minus(const fe& t1, const fe& u) {
     pm r;
     r.plus = F::add(t1, u);
-    r.minus = F::norm(F::template sub<8>(t1, u));
+    r.minus = F::norm(F::template sub<K>(t1, u));
     return r;
   }
 
@@ -91,10 +91,10 @@ template <class P> struct sw29 {
     }
   }
 
-  template <bool Fast = false>
+  template <bool Fast = false, int KMinus = 8>
   BZ_HD static point finish(const fe& t0, const fe& t1, const fe& u2, const fe& t3, const fe& t4,
                             const fe& u3) {
-    const pm s = plus_minus(t1, u2);
+    const pm s = plus_minus<KMinus>(t1, u2);
     point r;
     // every coordinate is a sum of two products: one Montgomery reduction each (F::mul2)
     if constexpr (!P::b3_negative) {
@@ -130,6 +130,53 @@ template <class P> struct sw29 {
     const fe y3 = F::add(prod<Fast>(q.x, p.Z), p.X);                         // B 2, V < 7.1
     t0 = F::add(F::add(t0, t0), t0);                                         // B 3, V < 3.3
     return finish<Fast>(t0, t1, mul_b3(p.Z), t3, t4, mul_b3(y3));
+  }
+
+  // The same addition for k_accumulate's bucket accumulators.  There p is the identity or a result
+  // of this very function, so its coordinates obey a much tighter invariant than the V < 6 of the
+  // general contract, (V_X, V_Y, V_Z) <= P::acc_v, and most of the partial reductions around the
+  // multiplications by |3b| can go (a `reduce` is ~50 instructions at N = 9):
+  //   bn254 (|3b| = 9, max_v 169), invariant (5, 4, 1.6): no reduce at all --
+  //     u2 = 9 Z1 < 14.4 (so t1 - u2 takes 16 p), u3 = 9 (x2 Z1 + X1) < 54.1, and with t3 < 5.16,
+  //     t4 < 5.02, 3 t0 < 3.09, t1 + u2 < 15.45, t1 - u2 + 16 p < 17.05:
+  //     X3 < (5.16 * 17.05 + 8 * 54.1) / 169 + 1 = 4.08, Y3 < (17.05 * 15.45 + 54.1 * 3.09) / 169 + 1
+  //     = 3.55, Z3 < (15.45 * 5.02 + 3.09 * 5.16) / 169 + 1 = 1.56;
+  //   bls12-381 (|3b| = 12, max_v 2520), invariant (2, 2, 1.1): no reduce -- u2 < 13.2, u3 < 36.1,
+  //     X3 < 1.15, Y3 < 1.14, Z3 < 1.03;
+  //   grumpkin (|3b| = 51, max_v 169), invariant (1.5, 1.5, 1.5): one reduce per product by 51
+  //     instead of three -- 51 Z1 < 76.5 and 51 (x2 Z1 + X1) < 128.1 both fit below max_v p, so
+  //     u2, u3 < 4 after one reduce: X3 < 1.21, Y3 < 1.37, Z3 < 1.23.
+  // Every output also satisfies the general contract (normalised, V < 6).  Host builds with
+  // BZ_MONT29_CHECK assert the invariant on entry and exit; tests/test_host_arith.py re-derives the
+  // three fixed points with exact fractions.
+  BZ_HD static fe mul_b3_acc(const fe& x) {
+    if constexpr (P::acc_reduce_b3) {
+      return F::reduce(F::mul_small(x, P::b3_abs));
+    } else {
+      return F::mul_small(x, P::b3_abs);
+    }
+  }
+  BZ_HD static void check_acc_invariant(const point& p) {
+    BZ_M29_ASSERT(F::v_below(p.X, P::acc_vx) && F::v_below(p.Y, P::acc_vy) &&
+                      F::v_below(p.Z, P::acc_vz),
+                  "add_mixed_acc: accumulator outside its invariant");
+    (void)p;
+  }
+  template <bool Fast = false>
+  BZ_HD static point add_mixed_acc(const point& p, const affine& q, bool negate) {
+    check_acc_invariant(p);
+    const fe y2 = F::select(q.y, F::norm(F::template neg<2>(q.y)), negate); // V <= 2
+    fe t0 = prod<Fast>(p.X, q.x);
+    const fe t1 = prod<Fast>(p.Y, y2);
+    fe t3 = prod<Fast>(F::add(q.x, y2), F::add(p.X, p.Y));
+    t3 = F::norm(F::template sub<4>(t3, F::add(t0, t1)));
+    const fe t4 = F::add(prod<Fast>(y2, p.Z), p.Y);                          // B 2
+    const fe y3 = F::add(prod<Fast>(q.x, p.Z), p.X);                         // B 2
+    t0 = F::add(F::add(t0, t0), t0);                                         // B 3
+    const point r =
+        finish<Fast, P::acc_minus_k>(t0, t1, mul_b3_acc(p.Z), t3, t4, mul_b3_acc(y3));
+    check_acc_invariant(r);
+    return r;
   }
 
   // p + q, Alg. 7
@@ -249,23 +296,34 @@ template <class P> struct sw29 {
   }
 };
 
+// acc_*: the bucket-accumulation form (add_mixed_acc): reduce after the products by |3b|?, the
+// multiple of p that t1 - |3b| Z1 takes, and the invariant of the accumulator's coordinates
 struct bn254_g1_29_params {
   using F = bn254_fq29;
   using G64 = bn254_g1;
   static constexpr u32 b3_abs = 9;
   static constexpr bool b3_negative = false;
+  static constexpr bool acc_reduce_b3 = false;
+  static constexpr int acc_minus_k = 16;
+  static constexpr double acc_vx = 5, acc_vy = 4, acc_vz = 1.6;
 };
 struct grumpkin_29_params {
   using F = grumpkin_fq29;
   using G64 = grumpkin_g;
   static constexpr u32 b3_abs = 51;
   static constexpr bool b3_negative = true;
+  static constexpr bool acc_reduce_b3 = true;
+  static constexpr int acc_minus_k = 8;
+  static constexpr double acc_vx = 1.5, acc_vy = 1.5, acc_vz = 1.5;
 };
 struct bls12_381_g1_28_params {
   using F = bls12_381_fp28;
   using G64 = bls12_381_g1;
   static constexpr u32 b3_abs = 12;
   static constexpr bool b3_negative = false;
+  static constexpr bool acc_reduce_b3 = false;
+  static constexpr int acc_minus_k = 16;
+  static constexpr double acc_vx = 2, acc_vy = 2, acc_vz = 1.1;
 };
 
 using bn254_g1_29 = sw29<bn254_g1_29_params>;

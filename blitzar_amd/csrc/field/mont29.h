@@ -87,6 +87,17 @@ template <class P> struct mont29 {
     (void)a;
 #endif
   }
+#if defined(BZ_MONT29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+  // X < bound * p ?  (check builds only; the ratio through long doubles, exact to ~2^-60)
+  static bool v_below(const fe& a, double bound) {
+    long double x = 0, p = 0;
+    for (int i = N - 1; i >= 0; --i) {
+      x = x * static_cast<long double>(u64{1} << LB) + a.v[i];
+      p = p * static_cast<long double>(u64{1} << LB) + P::p(i);
+    }
+    return x < static_cast<long double>(bound) * p;
+  }
+#endif
   BZ_HD static fe add(const fe& a, const fe& b) {
     fe h;
 #pragma unroll

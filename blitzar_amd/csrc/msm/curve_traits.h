@@ -342,9 +342,10 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
 #endif
     return o;
   }
+  // (k_accumulate only: `acc` is the identity or a result of this function, see add_mixed_acc)
   BZ_HD static void accumulate(point& acc, const operand& q, bool negate) {
     if (q.nonzero == 0) return;
-    acc = G29::template add_mixed<accumulate_pinned>(acc, q.a, negate);
+    acc = G29::template add_mixed_acc<accumulate_pinned>(acc, q.a, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];

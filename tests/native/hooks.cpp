@@ -402,6 +402,9 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
     G::G64::point p;                                                                               \
     std::memcpy(&p, start, sizeof(p));                                                             \
     G::point acc = G::from_point64(p);                                                             \
+    /* k_accumulate's form (add_mixed_acc, tighter invariant, fewer partial reductions): the same  \
+       residues coordinate by coordinate; its invariant is asserted inside (check build) */         \
+    G::point tight = acc;                                                                          \
     constexpr int W = G::N64;                                                                      \
     for (int i = 0; i < n; ++i) {                                                                  \
       G::affine q = G::affine_from_mont64(affine_xy + 2 * W * i, affine_xy + 2 * W * i + W, false); \
@@ -409,8 +412,13 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
       const G::point fast = G::template add_mixed<true>(acc, q, negate[i] != 0);                   \
       acc = G::add_mixed(acc, q, negate[i] != 0);                                                  \
       if (std::memcmp(&fast, &acc, sizeof(acc)) != 0) std::abort();                                \
+      const G::point tight_slow = G::template add_mixed_acc<false>(tight, q, negate[i] != 0);      \
+      tight = G::template add_mixed_acc<true>(tight, q, negate[i] != 0);                           \
+      if (std::memcmp(&tight_slow, &tight, sizeof(tight)) != 0) std::abort();                      \
     }                                                                                              \
     G::G64::point r = G::to_point64(acc);                                                          \
+    const G::G64::point rt = G::to_point64(tight);                                                 \
+    if (std::memcmp(&r, &rt, sizeof(r)) != 0) std::abort();                                        \
     std::memcpy(out, &r, sizeof(r));                                                               \
   }
 BZ_SW29_HOOKS(bn254, bn254_g1_29)

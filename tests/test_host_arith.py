@@ -420,6 +420,66 @@ def test_sw29_group_law_matches_reference(oracle, cid):
     xy = np.stack([gens[i, :16 * nl].view(np.uint64) for i in order])
     got = hooks.sw29_chain(cid, ident, xy, signs)
     assert np.array_equal(canon(got), canon(acc))
+    # a few thousand additions: the hook aborts if k_accumulate's form (add_mixed_acc) ever leaves
+    # its invariant or differs from the general form in any coordinate
+    long_order = rng.integers(0, len(order), 4000)
+    hooks.sw29_chain(cid, ident, xy[long_order], rng.integers(0, 2, 4000))
+
+
+@pytest.mark.parametrize("name,max_v,b3,negative,reduce_b3,k_minus,inv", [
+    ("bn254", 169, 9, False, False, 16, (5, 4, 1.6)),
+    ("bls12-381", 2520, 12, False, False, 16, (2, 2, 1.1)),
+    ("grumpkin", 169, 51, True, True, 8, (1.5, 1.5, 1.5)),
+])
+def test_bucket_accumulator_invariant_is_a_fixed_point(name, max_v, b3, negative, reduce_b3,
+                                                        k_minus, inv):
+    """curve/sw29.h add_mixed_acc drops partial reductions because k_accumulate's accumulator stays
+    inside (V_X, V_Y, V_Z) <= P::acc_v.  Random chains never reach the worst case, so the bounds of
+    every intermediate are propagated here with exact fractions, through the same steps, and every
+    precondition of field/mont29.h is checked on the way: the invariant must map into itself."""
+    from fractions import Fraction as Fr
+    M = Fr(max_v)
+    a, b, c = (Fr(v).limit_denominator(1000) for v in inv)
+
+    def mul(va, vb):      # Montgomery product: (V_a V_b p^2 + m p) / R < (V_a V_b / max_v + 1) p
+        assert va * vb / M + 1 < M
+        return va * vb / M + 1
+
+    def mul2(va, vb, vc, vd):
+        assert (va * vb + vc * vd) / M + 1 < M
+        return (va * vb + vc * vd) / M + 1
+
+    def sub(k, va, vb):   # a + k p - b needs V_b < k - 0.01
+        assert vb < k - Fr(1, 100)
+        return va + k
+
+    def mul_b3(v):
+        assert b3 * v < M                 # mul_small must fit below max_v p
+        return Fr(4) if reduce_b3 else b3 * v   # reduce: V < 4
+
+    y2 = Fr(2)                            # y or 2 p - y
+    t0 = mul(a, 1)
+    t1 = mul(b, y2)
+    t3 = sub(4, mul(1 + y2, a + b), t0 + t1)
+    t4 = mul(y2, c) + b
+    y3 = mul(1, c) + a
+    t0x3 = 3 * t0
+    u2, u3 = mul_b3(c), mul_b3(y3)
+    plus, minus = t1 + u2, sub(k_minus, t1, u2)
+    if not negative:
+        z3, t1m = plus, minus
+        t4n = sub(8, 0, t4)
+        x = mul2(t3, t1m, t4n, u3)
+        y = mul2(t1m, z3, u3, t0x3)
+        z = mul2(z3, t4, t0x3, t3)
+    else:
+        z3, t1m = minus, plus
+        t0n = sub(4, 0, t0x3)
+        x = mul2(t3, t1m, t4, u3)
+        y = mul2(t1m, z3, u3, t0n)
+        z = mul2(z3, t4, t0x3, t3)
+    assert x <= a and y <= b and z <= c, (name, float(x), float(y), float(z))
+    assert max(x, y, z) < 6               # the general contract of a point handed on
 
 
 def test_batched_inversion_tree_model():
