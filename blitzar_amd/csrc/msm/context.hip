@@ -62,6 +62,7 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_FRONT_PRIORITY", ctx->front_high_priority);
   flag("BLITZAR_AMD_DEDICATED_QUEUES", ctx->dedicated_queues);
   flag("BLITZAR_AMD_FAST_RECODE", ctx->fast_recode);
+  flag("BLITZAR_AMD_TAIL_LOW_PRIORITY", ctx->tail_low_priority);
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");

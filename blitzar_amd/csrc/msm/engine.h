@@ -165,10 +165,6 @@ struct msm_context {
   // BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.  A lone call never forks (every
   // fork / join pair costs ~25 us of stream bubbles).
   hipStream_t front = nullptr, acc = nullptr, tail = nullptr, tail2 = nullptr;
-  // the tail streams for callers on the NULL stream: plain non-blocking ones (a CU-masked stream is
-  // a blocking stream -- every operation the caller puts on the NULL stream would wait for it, and
-  // the tails it is meant to run beside: 2 columns x 2^20 rows 2.03 -> 2.40 ms per call)
-  hipStream_t tail_plain = nullptr, tail2_plain = nullptr;
   bool pipe_streams_made = false;
   stage_mark entry;
   stage_mark front_done[4], acc_done[4], reduce_done[4], horner_done[4];
@@ -179,16 +175,24 @@ struct msm_context {
   bool defer_tail = false;    // the next call runs in throughput mode (msm_context_defer_next_tail)
   bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: never fork
   bool overlap_front = false; // BLITZAR_AMD_OVERLAP_FRONT=1: front + accumulation on streams of their own
+  // The tail streams are non-blocking streams of the LOWEST priority.  Non-blocking: callers on the
+  // NULL stream must not meet a blocking stream (every NULL-stream launch takes a dependency on
+  // every blocking stream of the process, even an idle one: 1.00 -> 1.19 ms per call).  Lowest
+  // priority: the HIP runtime multiplexes the streams of a process over a few hardware queues PER
+  // PRIORITY LEVEL (4 by default) and packets of one queue execute in order, so an internal stream
+  // that lands on the queue of another one (PyTorch creates 32 normal-priority streams at its first
+  // side stream) inherits that stream's waits and the stages serialise again (1.12 -> 1.48 ms per
+  // step under torch); the lowest level is rarely used by anybody else.  And the tails have two
+  // calls' time to finish: whatever the caller's stream has ready goes first (a sequence of
+  // config-2 calls 1.009 -> 0.988 ms per call against tails on CU-masked queues of their own, the
+  // round's first answer to the multiplexing; profiles/round3_ab_tail_priority.log).
+  bool tail_low_priority = true; // BLITZAR_AMD_TAIL_LOW_PRIORITY=0: normal priority
   bool two_tail_streams = true; // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
   u32 front_cus = 0;          // BLITZAR_AMD_FRONT_CUS: CUs reserved for the front stream (0: no masks)
   bool front_high_priority = true; // BLITZAR_AMD_FRONT_PRIORITY=0: the front's queue at normal priority
-  // A stream with a hardware queue of its own.  The HIP runtime multiplexes the streams of a process
-  // over a few hardware queues per priority level (4 by default), and packets of one queue execute
-  // in order: an internal stream that lands on the queue of another one (a process with many
-  // streams: PyTorch creates 32 at its first side stream) inherits that stream's waits, and the
-  // stages the mode is meant to overlap serialise again (measured: 1.12 -> 1.48 ms per step under
-  // torch).  A stream created with a CU mask -- here the mask of ALL CUs -- always gets a queue of its
-  // own.  (Such streams are blocking streams: callers on the NULL stream get plain ones, below.)
+  // The front / accumulation streams of the overlap_front arrangement: a stream created with a CU
+  // mask -- here the mask of ALL CUs -- always gets a hardware queue of its own (see above).  Such
+  // streams are blocking streams, hence never for a caller on the NULL stream.
   bool dedicated_queues = true; // BLITZAR_AMD_DEDICATED_QUEUES=0: plain non-blocking streams
   bool fast_recode = true;      // BLITZAR_AMD_FAST_RECODE=0: the generic recode kernel for every shape
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
@@ -213,15 +217,12 @@ struct msm_context {
     return s;
   }
   void make_pipe_streams(bool null_caller) {
-    // (each kind only when a caller of that kind shows up: an idle blocking stream still costs
-    // every NULL-stream launch a cross-queue dependency -- 1.00 -> 1.19 ms per call)
-    if (null_caller && tail_plain == nullptr) {
-      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail_plain, hipStreamNonBlocking));
-      BZ_HIP_CHECK(hipStreamCreateWithFlags(&tail2_plain, hipStreamNonBlocking));
-    }
-    if (!null_caller && tail == nullptr) {
-      tail = make_stream();
-      tail2 = make_stream();
+    if (tail == nullptr) {
+      int least = 0, greatest = 0;
+      BZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      const int priority = tail_low_priority ? least : 0;
+      BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail, hipStreamNonBlocking, priority));
+      BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail2, hipStreamNonBlocking, priority));
     }
     if (pipe_streams_made || null_caller) return;
     pipe_streams_made = true;
@@ -298,7 +299,7 @@ struct msm_context {
       reduce_done[i].destroy();
       horner_done[i].destroy();
     }
-    for (hipStream_t s : {front, acc, tail2, tail, tail2_plain, tail_plain}) {
+    for (hipStream_t s : {front, acc, tail2, tail}) {
       if (s != nullptr) (void)hipStreamDestroy(s);
     }
   }
@@ -547,9 +548,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                 static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
                 static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
                 static_cast<u64>(d_addends == nullptr),
-                static_cast<u64>(mode.piped) | static_cast<u64>(mode.split) << 1 |
-                    // (the NULL stream's callers use tail streams of their own: a change joins first)
-                    static_cast<u64>(stream == nullptr) << 2}) {
+                static_cast<u64>(mode.piped) | static_cast<u64>(mode.split) << 1}) {
     layout = (layout ^ v) * 0x100000001b3ull;
   }
   if (ctx.any_pending() && layout != ctx.pipe_layout) {
@@ -562,10 +561,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   const u32 end_set = mode.piped ? static_cast<u32>(k % mode.end_sets()) : 0;
   hipStream_t fs = mode.split ? ctx.front : stream;
   hipStream_t as = mode.split ? ctx.acc : stream;
-  const bool null_caller = stream == nullptr;
-  hipStream_t rs = mode.piped ? (null_caller ? ctx.tail_plain : ctx.tail) : stream;
-  hipStream_t hs = !mode.piped ? stream
-                   : (ctx.two_tail_streams ? (null_caller ? ctx.tail2_plain : ctx.tail2) : rs);
+  hipStream_t rs = mode.piped ? ctx.tail : stream;
+  hipStream_t hs = !mode.piped ? stream : (ctx.two_tail_streams ? ctx.tail2 : rs);
   // completion marks of earlier batches (none outside the mode: join_all came first)
   auto earlier = [&](stage_mark* ring, u64 back) -> const stage_mark* {
     return mode.piped && k >= back ? &ring[(k - back) & 3] : nullptr;

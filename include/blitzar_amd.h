@@ -106,8 +106,8 @@ uint64_t bzamd_stage_timing_collect(double* out_ms);
  * such calls on the device have been enqueued on it, or after bzamd_pipeline_flush(stream): do not
  * read them earlier.  Calls with 64 or more columns ignore the request (their tails fill the
  * machine).  A pipelined sequence lives on ONE stream and one caller thread per device (the NULL
- * stream or a stream of the caller's own: the engine picks internal streams that do not
- * synchronise with it implicitly; changing between the two inside a sequence joins it first).
+ * stream or a stream of the caller's own: the engine's internal streams are non-blocking streams
+ * of the lowest priority, they synchronise with nobody implicitly).
  * (Measured on MI355X, 2^20 curve25519 rows: see DESIGN.md section 9.) */
 void bzamd_pipeline_next(void);
 void bzamd_pipeline_flush(void* stream);
