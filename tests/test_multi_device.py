@@ -218,3 +218,49 @@ def test_msm_multi_device_matches_oracle(gpu_backend, oracle):
         lib.bzamd_msm_multi_device(cid, outs, len(cols), desc, gptr)
         assert np.array_equal(out.cpu().numpy(), want)
         assert lib.bzamd_multi_device_exchange() == b"rccl"
+
+
+PIPELINE_BENCH = os.path.join(ROOT, "tools", "pipeline_bench", "_build", "pipeline_bench")
+
+
+@pytest.mark.gpu
+def test_stream_arrangements_of_the_throughput_mode_agree():
+    """the knobs that move the stages of consecutive calls between streams (read once per context,
+    hence one native process each: tools/pipeline_bench): never forking, one tail stream, tails at
+    normal priority, the measured-and-rejected front / accumulation streams with a priority queue
+    or with CU masks, the NULL stream as the caller's -- every step of every arrangement must
+    produce the same commitments as plain calls (the tool checks the steps against each other and
+    prints a hash over them)"""
+    if not os.path.exists(PIPELINE_BENCH):  # normally built by __graft_entry__.build()
+        src_dir = os.path.dirname(os.path.dirname(PIPELINE_BENCH))
+        lib_dir = os.path.join(ROOT, "blitzar_amd", "lib")
+        os.makedirs(os.path.dirname(PIPELINE_BENCH), exist_ok=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + src_dir, os.path.join(src_dir, "pipeline_bench.cc"),
+                        "-L" + lib_dir, "-lblitzar_amd", "-Wl,-rpath," + lib_dir, "-o", PIPELINE_BENCH],
+                       check=True)
+    arrangements = [
+        ({"BLITZAR_AMD_OVERLAP_TAILS": "0"}, []),
+        ({}, []),
+        ({}, ["--null-stream"]),
+        ({"BLITZAR_AMD_TAIL_STREAMS": "1"}, []),
+        ({"BLITZAR_AMD_TAIL_LOW_PRIORITY": "0"}, []),
+        ({"BLITZAR_AMD_OVERLAP_FRONT": "1"}, []),
+        ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_PRIORITY": "0",
+          "BLITZAR_AMD_DEDICATED_QUEUES": "0"}, []),
+        ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_CUS": "64"}, []),
+    ]
+    for curve, log2n, columns in ((0, 15, 1), (2, 13, 3)):
+        hashes = set()
+        for env_extra, flags in arrangements:
+            env = {k: v for k, v in os.environ.items() if not k.startswith("BLITZAR_AMD_")}
+            env["BLITZAR_AMD_NUM_DEVICES"] = "1"
+            env.update(env_extra)
+            r = subprocess.run([PIPELINE_BENCH, "--curve", str(curve), "--log2n", str(log2n),
+                                "--columns", str(columns), "--steps", "12", "--warmup", "3"] + flags,
+                               env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (env_extra, r.stdout[-2000:], r.stderr[-2000:])
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            assert line["outputs_agree"], (env_extra, line)
+            hashes.add(line["hash"])
+        assert len(hashes) == 1, hashes
