@@ -1093,6 +1093,12 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   };
   typename C::addend staged = gather(e_cur);
   for (u32 i = lo; i < hi; ++i) {
+    // the staged row first: the waits hipcc puts in front of its registers count every memory
+    // operation of the wavefront in order, so behind the flush block they would also wait for the
+    // block's nine stores to complete (curve25519 k_accumulate 0.629 -> 0.625 ms alone, 0.655 ->
+    // 0.648 in a sequence; the Weierstrass kernels unchanged)
+    const typename C::operand q = C::stage(staged);
+    const bool negate = (e_cur >> 31) != 0;
     if (i == b_end) {
       *flush_to = acc;
       ++b;
@@ -1106,8 +1112,6 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
       acc = C::identity();
     }
     next_end = ends[b < last_bucket ? b + 1 : last_bucket];
-    const typename C::operand q = C::stage(staged);
-    const bool negate = (e_cur >> 31) != 0;
     // the gather is unconditional (the last iteration re-reads its own row, a cache hit): a load
     // under `if (i + 1 < hi)` writes its registers in some lanes only, and hipcc then keeps two
     // copies of the row and moves it back and forth (bn254: 16 v_mov_b64 per iteration)
