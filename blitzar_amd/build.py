@@ -21,7 +21,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [
     "msm/msm_curve25519.hip",
+    "msm/msm_curve25519_accumulate.hip",
     "msm/msm_bls12_381.hip",
+    "msm/msm_bls12_381_accumulate.hip",
+    "msm/msm_bn254_accumulate.hip",
+    "msm/msm_grumpkin_accumulate.hip",
     "msm/msm_bn254.hip",
     "msm/msm_grumpkin.hip",
     "msm/context.hip",
@@ -32,6 +36,27 @@ SOURCES = [
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + ROOT,
          "-Wno-unused-result"]
+# Instruction scheduling per translation unit (measured on MI355X, A/B on one box,
+# profiles/round3_ab_sched_strategy.log).  hipcc's default strategy schedules for occupancy and
+# pads every dependent v_mad_u64_u32 pair it could not separate with an s_nop; "max-ilp" fills
+# those slots with independent instructions at the price of registers:
+#   * the Weierstrass accumulation loops lose 1200 of their 1400 s_nop per addition and still fit
+#     their wave budget (bn254 160, grumpkin 168, bls12-381 203 VGPRs): k_accumulate -3.6 % / -3.1 %
+#     / -1.8 %;
+#   * the curve25519 loops spill under max-ilp at three waves per SIMD (the Z = 1 form: 0.583 ->
+#     0.602 ms); they take the default strategy with a launch bound of two waves instead, which
+#     drops 145 of 429 s_nop at the same 140 VGPRs (still three waves resident): -1.6 %;
+#   * the other curve25519 kernels are latency chains on few wavefronts (k_reduce, k_horner): max-ilp
+#     0.198 -> 0.183 and 0.189 -> 0.183 ms, a lone config-2 call 1.187 -> 1.155 ms;
+#   * the other Weierstrass kernels keep the default (grumpkin's k_reduce: +23 % under max-ilp).
+MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+TU_FLAGS = {
+    "msm/msm_curve25519.hip": MAX_ILP,
+    "msm/msm_curve25519_accumulate.hip": ["-DBZ_ACC_WAVES_ED=2"],
+    "msm/msm_bls12_381_accumulate.hip": MAX_ILP,
+    "msm/msm_bn254_accumulate.hip": MAX_ILP,
+    "msm/msm_grumpkin_accumulate.hip": MAX_ILP,
+}
 # A/B variants (tools/prof/ab_env.sh): BZ_VARIANT=<tag> builds blitzar_amd/lib/variants/<tag>/ with
 # BZ_EXTRA_FLAGS (e.g. "-DBZ_F29_MAD_MODE=0") appended; the default library is untouched
 VARIANT = os.environ.get("BZ_VARIANT")
@@ -56,7 +81,7 @@ def _compile(src, newest_header, force):
             and os.path.getmtime(obj) >= max(os.path.getmtime(path), newest_header)):
         return obj, False
     t0 = time.time()
-    subprocess.run([HIPCC, *FLAGS, "-c", path, "-o", obj], check=True)
+    subprocess.run([HIPCC, *FLAGS, *TU_FLAGS.get(src, []), "-c", path, "-o", obj], check=True)
     print(f"[blitzar_amd] compiled {src} in {time.time() - t0:.0f}s", flush=True)
     return obj, True
 

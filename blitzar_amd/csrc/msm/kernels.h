@@ -1140,6 +1140,16 @@ __global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_si
   if (owned || write_head) *flush_to = acc;
 }
 
+// k_accumulate<C> is instantiated in a translation unit of its own per curve
+// (msm_<curve>_accumulate.hip), which is compiled with the instruction-scheduling strategy that
+// suits this one loop (blitzar_amd/build.py, TU_FLAGS); the TU that launches it declares the
+// instantiation with this macro
+#define BZ_ACCUMULATE_INSTANCE(KEYWORD, C)                                                         \
+  KEYWORD template __global__ void k_accumulate<C>(                                                \
+      typename C::point* __restrict__, typename C::point* __restrict__, const u32* __restrict__,   \
+      const u32* __restrict__, const u32* __restrict__, const typename C::addend* __restrict__,    \
+      const task_desc* __restrict__)
+
 // complete sum of bucket b of a task: the owner's partial plus the heads of the following
 // segments the bucket extends into.  Whole segments of one wavefront (64 consecutive segments)
 // were folded into the first of them by k_accumulate.

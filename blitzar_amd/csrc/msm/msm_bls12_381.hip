@@ -7,5 +7,6 @@
 #include "blitzar_amd/csrc/msm/curve_tu.h"
 
 namespace bz {
+BZ_ACCUMULATE_INSTANCE(extern, bls12_381_msm); // msm_bls12_381_accumulate.hip
 const curve_vtable& bls12_381_vtable() { return curve_tu<bls12_381_msm>::vtable(); }
 } // namespace bz

@@ -1,0 +1,10 @@
+// gfx950 code object of k_accumulate for bls12_381: the bucket accumulation loop, 65-85 % of every
+// MSM, in a translation unit of its own so that it can be compiled with the scheduling strategy
+// that suits it (blitzar_amd/build.py, TU_FLAGS) without touching the other kernels of the curve.
+#define BZ_MONT29_MAD_MODE 1 // the order of the Montgomery columns pinned, as in msm_bls12_381.hip
+#include "blitzar_amd/csrc/msm/curve_traits.h"
+#include "blitzar_amd/csrc/msm/kernels.h"
+
+namespace bz {
+BZ_ACCUMULATE_INSTANCE(, bls12_381_msm);
+} // namespace bz

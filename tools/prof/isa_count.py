@@ -25,8 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from blitzar_amd import build as bz_build  # noqa: E402  (FLAGS, HIPCC)
 
-TUS = {"curve25519": "msm/msm_curve25519.hip", "bls12_381": "msm/msm_bls12_381.hip",
-       "bn254": "msm/msm_bn254.hip", "grumpkin": "msm/msm_grumpkin.hip"}
+TUS = {"curve25519": "msm/msm_curve25519_accumulate.hip",
+       "bls12_381": "msm/msm_bls12_381_accumulate.hip", "bn254": "msm/msm_bn254_accumulate.hip",
+       "grumpkin": "msm/msm_grumpkin_accumulate.hip"}
 
 
 def classify(op):
@@ -122,7 +123,9 @@ def analyse(asm_path):
 def compile_tu(args):
     tu, flags, outdir = args
     dst = os.path.join(outdir, os.path.basename(tu).replace(".hip", ".s"))
-    subprocess.run([bz_build.HIPCC, *bz_build.FLAGS, *flags, "-S", "--offload-device-only",
+    # with the flags the library is built with for this translation unit (build.py, TU_FLAGS)
+    subprocess.run([bz_build.HIPCC, *bz_build.FLAGS, *bz_build.TU_FLAGS.get(tu, []), *flags, "-S",
+                    "--offload-device-only",
                     os.path.join(bz_build.CSRC, tu), "-o", dst], check=True)
     return dst
 
@@ -152,8 +155,9 @@ def main():
     tus = {c: t for c, t in TUS.items() if only is None or c in only}
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(tus)) as ex:
         paths = list(ex.map(compile_tu, [(t, flags, outdir) for t in tus.values()]))
-    result = {"source": "tools/prof/isa_count.py: hipcc -S --offload-device-only of msm/msm_<curve>.hip "
-                        "with the flags of blitzar_amd/build.py" + (" + " + " ".join(flags) if flags else ""),
+    result = {"source": "tools/prof/isa_count.py: hipcc -S --offload-device-only of "
+                        "msm/msm_<curve>_accumulate.hip with the flags of blitzar_amd/build.py "
+                        "(FLAGS + TU_FLAGS)" + (" + " + " ".join(flags) if flags else ""),
               "kernels": {}}
     for p in paths:
         result["kernels"].update(analyse(p))
