@@ -412,6 +412,7 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   mode.split = mode.piped && ctx.overlap_front && stream != nullptr;
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
+  tune.in_sequence = mode.piped;
   bool any_signed = false;
   for (const auto& c : cols) any_signed = any_signed || c.is_signed;
   // Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.

@@ -68,8 +68,16 @@ constexpr u32 kReduceSegmentLog2 = BZ_REDUCE_SEGMENT_LOG2;
 constexpr u32 kReduceSegmentLog2Max = BZ_REDUCE_SEGMENT_LOG2_MAX;
 // lanes that fill the machine twice over (1024 SIMDs x 64 lanes x 2 waves)
 constexpr u64 kReduceFillLanes = 131072;
-inline u32 choose_reduce_segment_log2(u64 total_buckets, u32 max_task_buckets) {
-  u32 s = kReduceSegmentLog2;
+// `in_sequence`: a call in throughput mode (msm_context).  Its k_reduce runs beside the next call
+// and has a whole step to finish, so what counts is not the length of its dependent chain but the
+// work it takes out of a machine that runs at its package power limit: twice the
+// buckets per lane, ~20 % fewer additions (per call in sequence, profiles/round3_ab_reduce_in_sequence.log:
+// config 2 0.987 -> 0.978 ms, on resident generators 0.892 -> 0.871, one bls12-381 column of 2^22
+// rows 12.6 -> 11.8; a lone k_reduce of this geometry takes 0.38 instead of 0.20 ms, which is why
+// lone calls keep the shorter chain).
+inline u32 choose_reduce_segment_log2(u64 total_buckets, u32 max_task_buckets,
+                                      bool in_sequence = false) {
+  u32 s = kReduceSegmentLog2 + (in_sequence ? 1 : 0);
   // narrow columns (bytes, booleans: 128..1024 buckets per task) have one block per task anyway:
   // fewer buckets per lane, down to one, shorten its chain (a 1-byte column of 2^20 rows: k_reduce
   // 0.25 -> 0.1 ms of a 0.6 ms call)
@@ -163,6 +171,7 @@ struct msm_tuning {
   size_t throughput_columns = 4;
   double throughput_bucket_cost = BZ_THROUGHPUT_BUCKET_COST;
   u32 force_window_bits = 0;         // tests (bzamd_set_window_bits): this width wherever a column allows it
+  bool in_sequence = false; // set per call by msm_enqueue: the call runs in throughput mode
   u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
   u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
   // throughput mode (engine.h, msm_context): calls with this many columns or more ignore
@@ -374,7 +383,11 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
   }
   plan.reduce_segment_log2 = tune.force_reduce_segment_log2 != 0
                                  ? tune.force_reduce_segment_log2
-                                 : choose_reduce_segment_log2(plan.total_buckets, plan.max_task_buckets);
+                                 : choose_reduce_segment_log2(
+                                       plan.total_buckets, plan.max_task_buckets,
+                                       // (short columns are all tail even in a sequence: 2^16 rows
+                                       // 0.285 -> 0.351 ms per call with the longer chain)
+                                       tune.in_sequence && plan.total_entries >= (u64{1} << 23));
   return plan;
 }
 

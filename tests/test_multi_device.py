@@ -250,7 +250,8 @@ def test_stream_arrangements_of_the_throughput_mode_agree():
           "BLITZAR_AMD_DEDICATED_QUEUES": "0"}, []),
         ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_CUS": "64"}, []),
     ]
-    for curve, log2n, columns in ((0, 15, 1), (2, 13, 3)):
+    # (2^19 rows x 16 windows: long enough for the throughput mode's own reduce geometry, plan.h)
+    for curve, log2n, columns in ((0, 15, 1), (2, 13, 3), (0, 19, 1)):
         hashes = set()
         for env_extra, flags in arrangements:
             env = {k: v for k, v in os.environ.items() if not k.startswith("BLITZAR_AMD_")}
