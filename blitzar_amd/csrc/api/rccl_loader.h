@@ -21,12 +21,16 @@ struct rccl_api {
   const char* (*get_error_string)(ncclResult_t) = nullptr;
   const char* loaded_from = "";
 
-  // nullptr when no RCCL can be found (the caller falls back to peer copies)
+  // nullptr when no RCCL can be found (the caller falls back to peer copies); loaded once, by
+  // whichever thread asks first (initialisation of a function-local static)
   static rccl_api* get() {
+    static rccl_api* const loaded = load();
+    return loaded;
+  }
+
+private:
+  static rccl_api* load() {
     static rccl_api api;
-    static bool tried = false;
-    if (tried) return api.handle != nullptr ? &api : nullptr;
-    tried = true;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names) {
       api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
