@@ -162,12 +162,13 @@ def recode_words32(row_bytes, skew, bit_offset, bit_width, is_signed, window_bit
     return digits
 
 
-def plan(ns, bit_widths, signed, max_window_bits=16):
+def plan(ns, bit_widths, signed, max_window_bits=16, in_sequence=False):
     k = len(ns)
     per = np.zeros((k, 6), np.uint32)
     totals = np.zeros(8, np.uint64)
     lib().bz_plan(_p(per), _p(totals), _p(_c(ns)), _p(_c(bit_widths, np.uint32)),
-                  _p(_c(signed, np.int32)), ctypes.c_uint32(k), ctypes.c_uint32(max_window_bits))
+                  _p(_c(signed, np.int32)), ctypes.c_uint32(k), ctypes.c_uint32(max_window_bits),
+                  ctypes.c_int(1 if in_sequence else 0))
     return per, totals
 
 

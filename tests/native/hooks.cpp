@@ -172,13 +172,14 @@ int bz_recode_words32(int* digits, const u8* row, u32 skew, u32 bit_offset, u32 
 // group_bits}; totals {tasks, total_buckets, total_entries, total_segments, rows covered,
 // total_groups, log2 entries per accumulate lane, log2 buckets per reduce lane}
 void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, const int* is_signed,
-             u32 num_columns, u32 max_window_bits) {
+             u32 num_columns, u32 max_window_bits, int in_sequence) {
   std::vector<host_column> cols(num_columns);
   for (u32 i = 0; i < num_columns; ++i) {
     cols[i] = host_column{nullptr, n[i], (bit_width[i] + 7) / 8, 0, bit_width[i], is_signed[i] != 0};
   }
   msm_tuning tune;
   tune.max_window_bits = max_window_bits;
+  tune.in_sequence = in_sequence != 0; // the call runs in throughput mode (msm_enqueue sets this)
   msm_plan plan = make_msm_plan(cols, tune);
   for (u32 i = 0; i < num_columns; ++i) {
     const column_desc& c = plan.columns[i];

@@ -188,6 +188,22 @@ def test_planner_invariants():
     assert totals[6:].tolist() == [7, 3]
     per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256)
     assert totals[6:].tolist() == [7, 6] and per[0][0] == 16
+    # a call in throughput mode: k_reduce has a whole step to finish beside the next call and the
+    # machine runs at its power limit, so long columns take twice the buckets per lane (fewer
+    # additions); short ones (under 2^23 entries: their step is all tail) and many-column calls
+    # that are at the throughput geometry anyway keep theirs
+    _, totals = hooks.plan([1 << 20], [256], [0], in_sequence=True)
+    assert totals[6:].tolist() == [5, 4]
+    _, totals = hooks.plan([1 << 22], [256], [0], in_sequence=True)
+    assert totals[6:].tolist() == [7, 4]
+    _, totals = hooks.plan([1 << 18], [256], [0], in_sequence=True)
+    assert totals[7] == 3
+    for columns, plain, in_sequence in ((2, 3, 4), (4, 4, 4), (32, 6, 6)):
+        shape = ([1 << 20] * columns, [256] * columns, [0] * columns)
+        assert hooks.plan(*shape)[1][7] == plain
+        assert hooks.plan(*shape, in_sequence=True)[1][7] == in_sequence
+    _, totals = hooks.plan([1 << 24], [8], [0], in_sequence=True)   # 128 buckets per task
+    assert totals[7] == 0
     # narrow columns: 256 (1 byte) or 1024 (4 bytes) buckets per task spread over the 256 lanes
     # of their one reduce block, down to one bucket per lane
     _, totals = hooks.plan([1 << 20], [8], [0])
