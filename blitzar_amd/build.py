@@ -22,6 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = [
     "msm/msm_curve25519.hip",
     "msm/msm_curve25519_accumulate.hip",
+    "msm/msm_curve25519_niels_accumulate.hip",
     "msm/msm_bls12_381.hip",
     "msm/msm_bls12_381_accumulate.hip",
     "msm/msm_bn254_accumulate.hip",
@@ -45,7 +46,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + ROOT,
 #     / -1.8 %;
 #   * the curve25519 loops spill under max-ilp at three waves per SIMD (the Z = 1 form: 0.583 ->
 #     0.602 ms); they take the default strategy with a launch bound of two waves instead, which
-#     drops 145 of 429 s_nop at the same 140 VGPRs (still three waves resident): -1.6 %;
+#     drops 145 of 429 s_nop at the same 140 VGPRs (still three waves resident): -1.6 %; the
+#     "iterative-ilp" strategy fits the Z = 1 loop into three waves without a spill (159 VGPRs, 25
+#     s_nop left: 0.578 -> 0.567 ms, a sequence on resident generators 0.869 -> 0.855 ms per call)
+#     but spills 92 bytes in the caller-generators loop, which then loses in a sequence (0.966 ->
+#     0.975) what it gains alone (0.623 -> 0.605);
 #   * the other curve25519 kernels are latency chains on few wavefronts (k_reduce, k_horner): max-ilp
 #     0.198 -> 0.183 and 0.189 -> 0.183 ms, a lone config-2 call 1.187 -> 1.155 ms;
 #   * the other Weierstrass kernels keep the default (grumpkin's k_reduce: +23 % under max-ilp).
@@ -53,6 +58,7 @@ MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 TU_FLAGS = {
     "msm/msm_curve25519.hip": MAX_ILP,
     "msm/msm_curve25519_accumulate.hip": ["-DBZ_ACC_WAVES_ED=2"],
+    "msm/msm_curve25519_niels_accumulate.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
     "msm/msm_bls12_381_accumulate.hip": MAX_ILP,
     "msm/msm_bn254_accumulate.hip": MAX_ILP,
     "msm/msm_grumpkin_accumulate.hip": MAX_ILP,

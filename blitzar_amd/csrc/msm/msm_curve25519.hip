@@ -3,7 +3,7 @@
 
 namespace bz {
 BZ_ACCUMULATE_INSTANCE(extern, ed25519_msm); // msm_curve25519_accumulate.hip
-BZ_ACCUMULATE_INSTANCE(extern, ed25519_niels_msm); // msm_curve25519_accumulate.hip
+BZ_ACCUMULATE_INSTANCE(extern, ed25519_niels_msm); // msm_curve25519_niels_accumulate.hip
 // Per-call caller generators keep the projective (Y+X, Y-X, Z, 2dT) addends: normalising them to
 // Z = 1 on every call (k_prepare_addends_batched, one shared inversion per 1024 generators) makes
 // k_accumulate 8 % faster (0.72 -> 0.66 ms at config 2) but the shared inversion is a 50-80 us

@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 from blitzar_amd import build as bz_build  # noqa: E402  (FLAGS, HIPCC)
 
 TUS = {"curve25519": "msm/msm_curve25519_accumulate.hip",
+       "curve25519_niels": "msm/msm_curve25519_niels_accumulate.hip",
        "bls12_381": "msm/msm_bls12_381_accumulate.hip", "bn254": "msm/msm_bn254_accumulate.hip",
        "grumpkin": "msm/msm_grumpkin_accumulate.hip"}
 
