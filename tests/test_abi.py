@@ -147,3 +147,27 @@ def test_gpu_backend_without_gpu_fails_loudly():
 
 def test_numpy_views_are_little_endian_host():
     assert np.dtype(np.uint32).byteorder in ("=", "<") and sys.byteorder == "little"
+
+
+def test_build_recipe_is_consistent():
+    """blitzar_amd/build.py: every per-unit flag set names a source that is built, every source
+    exists, and every curve's accumulation loop has its translation unit (the units that launch
+    k_accumulate only declare the instantiation: a missing one would be a link error on the box)"""
+    import os
+    from blitzar_amd import build
+    for src in build.SOURCES:
+        assert os.path.exists(os.path.join(build.CSRC, src)), src
+    assert set(build.TU_FLAGS) <= set(build.SOURCES)
+    accumulate_units = [s for s in build.SOURCES if s.endswith("_accumulate.hip")]
+    instances = ""
+    for s in accumulate_units:
+        with open(os.path.join(build.CSRC, s)) as fh:
+            instances += fh.read()
+    for curve in ("ed25519_msm", "ed25519_niels_msm", "bls12_381_msm", "bn254_msm", "grumpkin_msm"):
+        assert f"BZ_ACCUMULATE_INSTANCE(, {curve});" in instances, curve
+        declared = 0
+        for s in build.SOURCES:
+            if s.startswith("msm/msm_") and not s.endswith("_accumulate.hip"):
+                with open(os.path.join(build.CSRC, s)) as fh:
+                    declared += fh.read().count(f"BZ_ACCUMULATE_INSTANCE(extern, {curve});")
+        assert declared == 1, curve
