@@ -196,6 +196,78 @@ def partition_table(curve_id, window_width, generators_projective):
 
 
 #--------------------------------------------------------------------------------------------------
+# fixed-base MSM (oracle/ref/ref_fixed_base.cc: the reference's own host path -- its partition-table
+# accessor, mtxpp2::multiexponentiate, partition_product and reduce_products -- compiled in place)
+#--------------------------------------------------------------------------------------------------
+_PROJ_WORDS = {0: 20, 1: 18, 2: 12, 3: 12}
+
+
+class FixedHandle:
+    """what cpu_backend keeps behind a sxt_multiexp_handle (cpu_backend.cc:196-211): an
+    in_memory_partition_table_accessor over the reference's own table"""
+
+    def __init__(self, curve_id, generators_projective=None, window_width=16, filename=None):
+        self.curve_id = curve_id
+        L = lib()
+        L.ref_fixed_handle_new.restype = ctypes.c_void_p
+        L.ref_fixed_handle_from_file.restype = ctypes.c_void_p
+        if filename is not None:
+            self._h = ctypes.c_void_p(L.ref_fixed_handle_from_file(ctypes.c_uint(curve_id),
+                                                                    filename.encode()))
+            return
+        g = np.ascontiguousarray(generators_projective, dtype=np.uint64).reshape(
+            -1, _PROJ_WORDS[curve_id])
+        self.n = g.shape[0]
+        self._h = ctypes.c_void_p(L.ref_fixed_handle_new(ctypes.c_uint(curve_id), _p(g),
+                                                          ctypes.c_uint(self.n),
+                                                          ctypes.c_uint(window_width)))
+
+    def write_to_file(self, filename):
+        lib().ref_fixed_handle_write(self._h, filename.encode())
+
+    def close(self):
+        if self._h is not None:
+            lib().ref_fixed_handle_free(self._h)
+            self._h = None
+
+    def _out(self, num_outputs):
+        return np.zeros((num_outputs, _PROJ_WORDS[self.curve_id]), dtype=np.uint64)
+
+    @staticmethod
+    def _fn(name, gpu_flow):
+        # gpu_flow: the reference's GPU control flow (async_multiexponentiate + scheduler) executed
+        # on the host stand-ins instead of its host loop -- see ref_fixed_base.cc
+        return getattr(lib(), name + ("_async" if gpu_flow else ""))
+
+    def multiexponentiation(self, element_num_bytes, num_outputs, n, scalars, gpu_flow=False):
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1)
+        assert s.size == element_num_bytes * num_outputs * n
+        res = self._out(num_outputs)
+        self._fn("ref_fixed_multiexponentiation", gpu_flow)(_p(res), self._h, ctypes.c_uint(element_num_bytes),
+                                            ctypes.c_uint(num_outputs), ctypes.c_uint(n), _p(s))
+        return res
+
+    def packed_multiexponentiation(self, bit_table, n, scalars, gpu_flow=False):
+        bt = np.ascontiguousarray(bit_table, dtype=np.uint32)
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1)
+        assert s.size == (int(bt.sum()) + 7) // 8 * n
+        res = self._out(bt.size)
+        self._fn("ref_fixed_packed_multiexponentiation", gpu_flow)(
+            _p(res), self._h, _p(bt), ctypes.c_uint(bt.size), ctypes.c_uint(n), _p(s))
+        return res
+
+    def vlen_multiexponentiation(self, bit_table, lengths, scalars, gpu_flow=False):
+        bt = np.ascontiguousarray(bit_table, dtype=np.uint32)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1)
+        assert s.size >= (int(bt.sum()) + 7) // 8 * int(ln.max(initial=0))
+        res = self._out(bt.size)
+        self._fn("ref_fixed_vlen_multiexponentiation", gpu_flow)(
+            _p(res), self._h, _p(bt), _p(ln), ctypes.c_uint(bt.size), _p(s))
+        return res
+
+
+#--------------------------------------------------------------------------------------------------
 # inner-product argument (oracle/ref/ref_inner_product.cc: the reference's own prover / verifier)
 #--------------------------------------------------------------------------------------------------
 def transcript_new(label):

@@ -6,7 +6,10 @@ restates the one part that cannot be compiled here.  Checks:
   * homomorphism (third KAT = sum of the first two, as the Rust test asserts, :77-79),
   * the committed golden fixtures are exactly what the oracle produces today,
   * the fixed-base restatement agrees with the reference's variable-base backend on the same
-    scalars unpacked to columns, and with the known answers of cbindings/fixed_pedersen.t.cc.
+    scalars unpacked to columns, and with the known answers of cbindings/fixed_pedersen.t.cc,
+  * the reference's OWN fixed-base path compiled in place (oracle/ref/ref_fixed_base.cc: its
+    accessor, mtxpp2::multiexponentiate, and -- on host stand-ins for the CUDA runtime -- its GPU
+    control flow async_multiexponentiate) gives the same answers, tables and files.
 """
 import hashlib
 import os
@@ -119,3 +122,126 @@ def test_golden_fixed_base_fixture(oracle, cid):
                                        GOLDEN[f"curve{cid}_fixed_scalars"])
     got = np.stack([oracle.canonical(cid, r).view(np.uint8).reshape(-1) for r in res])
     assert np.array_equal(got, GOLDEN[f"curve{cid}_fixed_canonical"])
+
+
+#--------------------------------------------------------------------------------------------------
+# the reference's own fixed-base path, compiled in place (round 4)
+#--------------------------------------------------------------------------------------------------
+def _canon_all(oracle, cid, res):
+    return np.stack([oracle.canonical(cid, r).view(np.uint8).reshape(-1) for r in res])
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_compiled_fixed_base_matches_restatement_and_variable_base(oracle, cid):
+    from oracle import fixed_base
+    rng = np.random.default_rng(7400 + cid)
+    m = 43  # not a multiple of any window width used below
+    gens = util.generators_for(cid, m)
+    proj = gens if cid == 0 else oracle.affine_to_projective(cid, gens)
+    for w, bit_table in ((4, [3, 1, 8, 13, 64, 256]), (3, [1, 1, 7]), (8, [9, 32, 8])):
+        h = oracle.FixedHandle(cid, proj, w)
+        table = fixed_base.PartitionTable(cid, proj, w)
+        row = (sum(bit_table) + 7) // 8
+        scalars = rng.integers(0, 256, (m, row), dtype=np.uint8)
+        want = oracle.commit(cid, fixed_base.unpack_columns(bit_table, m, scalars), gens)
+        restated = _canon_all(oracle, cid, fixed_base.multiexponentiate(table, bit_table, m, scalars))
+        for gpu_flow in (False, True):
+            got = _canon_all(oracle, cid, h.packed_multiexponentiation(bit_table, m, scalars,
+                                                                        gpu_flow=gpu_flow))
+            assert np.array_equal(got, restated)
+            assert np.array_equal(got[:, :want.shape[1]], want)
+        h.close()
+    # byte-aligned outputs
+    h = oracle.FixedHandle(cid, proj, 4)
+    table = fixed_base.PartitionTable(cid, proj, 4)
+    scalars = rng.integers(0, 256, (m, 3 * 5), dtype=np.uint8)
+    restated = _canon_all(oracle, cid, fixed_base.multiexponentiate_bytes(table, 3, 5, m, scalars))
+    for gpu_flow in (False, True):
+        got = _canon_all(oracle, cid, h.multiexponentiation(3, 5, m, scalars, gpu_flow=gpu_flow))
+        assert np.array_equal(got, restated)
+    # ascending lengths; no zero-length output here, so the host loop is sound too
+    bit_table, lengths = [5, 2, 16, 40], [2, 4, 11, 43]
+    row = (sum(bit_table) + 7) // 8
+    scalars = rng.integers(0, 256, (m, row), dtype=np.uint8)
+    restated = _canon_all(oracle, cid,
+                          fixed_base.multiexponentiate(table, bit_table, m, scalars, lengths))
+    for gpu_flow in (False, True):
+        got = _canon_all(oracle, cid, h.vlen_multiexponentiation(bit_table, lengths, scalars,
+                                                                  gpu_flow=gpu_flow))
+        assert np.array_equal(got, restated)
+    h.close()
+
+
+@pytest.mark.parametrize("cid", [0, 2])
+def test_zero_length_outputs_follow_the_reference_gpu_flow(oracle, cid):
+    """the reference's host vlen loop mutates its product index inside the loop
+    (variable_length_partition_product.h:145-148) and goes wrong once an output has length zero;
+    its GPU lambda (:101-109) does not.  The restatement -- and the product -- follow the GPU
+    lambda, which is checked here through the reference's own async_multiexponentiate."""
+    from oracle import fixed_base
+    rng = np.random.default_rng(7500 + cid)
+    m = 37
+    gens = util.generators_for(cid, m)
+    proj = gens if cid == 0 else oracle.affine_to_projective(cid, gens)
+    h = oracle.FixedHandle(cid, proj, 4)
+    table = fixed_base.PartitionTable(cid, proj, 4)
+    bit_table, lengths = [4, 12, 1, 64], [0, 5, 5, 37]
+    scalars = rng.integers(0, 256, (m, (sum(bit_table) + 7) // 8), dtype=np.uint8)
+    restated = _canon_all(oracle, cid,
+                          fixed_base.multiexponentiate(table, bit_table, m, scalars, lengths))
+    got = _canon_all(oracle, cid, h.vlen_multiexponentiation(bit_table, lengths, scalars,
+                                                              gpu_flow=True))
+    assert np.array_equal(got, restated)
+    want = oracle.commit(cid, fixed_base.unpack_columns(bit_table, m, scalars, lengths), gens)
+    assert np.array_equal(got[:, :want.shape[1]], want)
+    h.close()
+
+
+def test_compiled_fixed_base_known_answers(oracle):
+    """cbindings/fixed_pedersen.t.cc:51-200 through the reference's own accessor and
+    multiexponentiate (window width 16, its default)"""
+    g = oracle.ristretto_generators(3, 7)
+
+    def lin(coeffs):
+        return oracle.commit(0, [(np.array(coeffs, dtype=np.uint64), False)], g)[0]
+
+    def canon(p):
+        return oracle.ristretto_compress(p)
+
+    h2 = oracle.FixedHandle(0, g[:2], 16)
+    for gpu_flow in (False, True):
+        r = h2.multiexponentiation(2, 1, 2, np.array([1, 0, 0, 2], np.uint8), gpu_flow=gpu_flow)
+        assert np.array_equal(canon(r[0]), lin([1, 512]))
+        r = h2.packed_multiexponentiation([3, 1], 2, np.array([0b1010, 0b0101], np.uint8),
+                                          gpu_flow=gpu_flow)
+        assert np.array_equal(canon(r[0]), lin([2, 5]))
+        assert np.array_equal(canon(r[1]), lin([1, 0]))
+        r = h2.vlen_multiexponentiation([3, 1], [1, 2], np.array([0b1011, 0b1101], np.uint8),
+                                        gpu_flow=gpu_flow)
+        assert np.array_equal(canon(r[0]), lin([3, 0]))
+        assert np.array_equal(canon(r[1]), lin([1, 1]))
+    h2.close()
+    h3 = oracle.FixedHandle(0, g, 16)
+    r = h3.packed_multiexponentiation([8], 3, np.array([1, 1, 1], np.uint8))
+    assert np.array_equal(canon(r[0]), lin([1, 1, 1]))
+    h3.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_compiled_accessor_files_match_restated_table(oracle, cid, tmp_path):
+    """write_to_file / the file constructor of in_memory_partition_table_accessor
+    (in_memory_partition_table_accessor.h:42-59,98-105) against the restated file format"""
+    from oracle import fixed_base
+    proj = GOLDEN[f"curve{cid}_fixed_projective_generators"]
+    h = oracle.FixedHandle(cid, proj, 4)
+    path = str(tmp_path / "table.bin")
+    h.write_to_file(path)
+    raw = open(path, "rb").read()
+    assert raw == fixed_base.PartitionTable(cid, proj, 4).file_bytes()
+    assert hashlib.sha256(raw).digest() == GOLDEN[f"curve{cid}_table_w4_sha256"].tobytes()
+    h2 = oracle.FixedHandle(cid, filename=path)
+    res = h2.packed_multiexponentiation(GOLDEN["fixed_bit_table"], proj.shape[0],
+                                        GOLDEN[f"curve{cid}_fixed_scalars"])
+    assert np.array_equal(_canon_all(oracle, cid, res), GOLDEN[f"curve{cid}_fixed_canonical"])
+    h.close()
+    h2.close()
