@@ -316,9 +316,9 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
     handle_s = time.perf_counter() - t0
     bit_table = wl.config5_bit_table(outputs)
     row_bytes = (int(bit_table.sum()) + 7) // 8
-    g = torch.Generator(device=dev)
-    g.manual_seed(5)
-    scalars = torch.randint(0, 256, (n, row_bytes), dtype=torch.uint8, device=dev, generator=g)
+    # the mt19937{0} byte stream of the reference benchmarks, row-major over the packed rows
+    # (3.3e9 draws: tools/mt19937 on all host threads)
+    scalars = torch.from_numpy(wl.mt19937_bytes(n * row_bytes).reshape(n, row_bytes)).to(dev)
     offs = (np.concatenate([[0], np.cumsum(bit_table)[:-1]]) // 8).astype(np.int64)
     wide = torch.from_numpy(offs[bit_table == 256] + 31).to(dev)
     scalars[:, wide] &= 0x0f
@@ -349,7 +349,9 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
              "bits_per_row": int(bit_table.sum()), "ms_per_call": dt * 1e3,
              "row_output_ops_per_s": ops / dt, "outputs_per_s": outputs / dt,
              "handle_creation_s": handle_s,
-             "data": "torch device generator (3.3e9 draws of a serial mt19937 take 83 s)",
+             "data": "mt19937{0} bytes (tools/mt19937: the one serial stream produced on all host "
+                     "threads by jump-ahead), the 256-bit fields masked to 252 bits; generators: "
+                     "SURVEY 8(d)'s chain g_i = g_{i-1} + g_0 built by the reference's own code",
              "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
              "verified": f"all {outputs} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
                          "encoded by the reference's curve code",
@@ -399,17 +401,20 @@ def run_configs(lib, oracle, args, dev, stream):
     # region -- over at least 10 calls)
     e3 = variable_base_config(lib, oracle, 1, "3: bls12-381 G1 MSM, n = 2^22, 252-bit scalars", 22,
                               1, s3, max(args.config_steps, 10), dev, stream, 15)
-    e3["data"] = "mt19937{0} bytes, top nibble masked; generators g_i = (i + 1) G"
+    e3["data"] = ("mt19937{0} bytes, top nibble masked; generators: SURVEY 8(d)'s chain g_0 = "
+                  "generate_random_element(rng{1, 2}), g_i = g_{i-1} + g_0, built by the reference's "
+                  "own code")
     entries.append(e3)
     del s3
-    g = torch.Generator(device=dev)
-    g.manual_seed(4)
-    s4 = torch.randint(0, 256, (256, 1 << 20, 32), dtype=torch.uint8, device=dev, generator=g)
-    s4[:, :, 31] &= 0x0f
+    # one mt19937{0} stream filling the 256 columns column-major (multi_commitment/benchmark.m.cc:
+    # 141-156), 2^33 draws: tools/mt19937 on all host threads
+    s4 = torch.from_numpy(wl.mt19937_scalars(256, 1 << 20, 32, top_mask=0x0f)).to(dev)
     e4 = variable_base_config(lib, oracle, 2, "4: bn254 G1 multi-commitment, 256 columns x 2^20 "
                               "rows (the whole config on ONE GPU)", 20, 256, s4, args.config_steps,
                               dev, stream, 15)
-    e4["data"] = "torch device generator (2^33 draws of a serial mt19937 take 215 s); g_i = (i + 1) G"
+    e4["data"] = ("mt19937{0} bytes, column-major, top nibble masked (tools/mt19937: the one serial "
+                  "stream on all host threads by jump-ahead); generators: SURVEY 8(d)'s chain "
+                  "g_i = g_{i-1} + g_0 built by the reference's own code")
     entries.append(e4)
     del s4
     torch.cuda.empty_cache()
@@ -423,10 +428,9 @@ def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll):
     cid, n, columns = 2, 1 << 20, 256
     per = columns // world
     begin = rank * per
-    g = torch.Generator(device=dev)
-    g.manual_seed(4000 + rank)
-    scalars = torch.randint(0, 256, (per, n, 32), dtype=torch.uint8, device=dev, generator=g)
-    scalars[:, :, 31] &= 0x0f
+    # this rank's columns of the ONE mt19937{0} stream of the config (jump-ahead to column `begin`)
+    scalars = torch.from_numpy(wl.mt19937_scalars(per, n, 32, top_mask=0x0f,
+                                                  first_column=begin)).to(dev)
     base, gens = wl.dlog_generators(lib, oracle, cid, n, dev, stream)
     out = torch.zeros((per, 72), dtype=torch.uint8, device=dev)
     gathered = torch.zeros((world * per, 72), dtype=torch.uint8, device=dev)

@@ -242,6 +242,28 @@ void ref_f51_invert(uint64_t* h, const uint64_t* f) {
     std::memcpy(static_cast<uint8_t*>(out) + sizeof(r.X), &r.Y, sizeof(r.Y));                      \
     static_cast<uint8_t*>(out)[2 * sizeof(r.X)] = r.infinity;                                      \
   }                                                                                                \
+  /* out[i] = affine(start + (i + 1) * step), i < count: the chain g_i = g_{i-1} + g_0 of big   */ \
+  /* synthetic generator sets -- the reference's add and to_element_affine in a    */ \
+  /* loop; `start` is overwritten with the last element so that a caller can go on               */ \
+  void ref_##PFX##_generator_chain(void* out, uint64_t* start, const uint64_t* step,               \
+                                   uint64_t count) {                                               \
+    TNS::element_p2 acc, g;                                                                        \
+    std::memcpy(&acc, start, sizeof(acc));                                                         \
+    std::memcpy(&g, step, sizeof(g));                                                              \
+    auto dst = static_cast<uint8_t*>(out);                                                         \
+    for (uint64_t i = 0; i < count; ++i, dst += sizeof(TNS::element_affine)) {                     \
+      TNS::element_p2 r;                                                                           \
+      ONS::add(r, acc, g);                                                                         \
+      TNS::element_affine a;                                                                       \
+      TNS::to_element_affine(a, r);                                                                \
+      std::memset(dst, 0, sizeof(a));                                                              \
+      std::memcpy(dst, &a.X, sizeof(a.X));                                                         \
+      std::memcpy(dst + sizeof(a.X), &a.Y, sizeof(a.Y));                                           \
+      dst[2 * sizeof(a.X)] = a.infinity;                                                           \
+      acc = r;                                                                                     \
+    }                                                                                              \
+    std::memcpy(start, &acc, sizeof(acc));                                                         \
+  }                                                                                                \
   void ref_##PFX##_msm_p2(uint64_t* out, uint32_t num_sequences, const seq_desc* descs,            \
                           const void* generators_affine) {                                         \
     /* host loop affine -> projective as cbindings/pedersen.cc:126-128 / :157-159 / :188-190 */    \

@@ -106,6 +106,19 @@ def random_affine(curve_id, seed1, seed2):
     return out
 
 
+def generator_chain(curve_id, start_p2, step_p2, count):
+    """affine(start + (i + 1) step) for i < count, C-ABI affine layout (ref_driver.cc: the
+    reference's add + to_element_affine in a loop; releases the GIL, so segments of a long chain
+    can run on host threads)"""
+    pfx, _, stride, _ = CURVES[curve_id]
+    out = np.zeros((count, stride), dtype=np.uint8)
+    start = np.ascontiguousarray(start_p2, dtype=np.uint64).copy()
+    step = np.ascontiguousarray(step_p2, dtype=np.uint64)
+    getattr(lib(), f"ref_{pfx}_generator_chain")(_p(out), _p(start), _p(step),
+                                                  ctypes.c_uint64(count))
+    return out, start
+
+
 def identity_affine(curve_id):
     """{0, R, infinity = 1} in C-ABI affine layout."""
     pfx, nl, stride, _ = CURVES[curve_id]

@@ -101,15 +101,11 @@ def test_config3_bls12_381_2_22_rows(gpu_backend, oracle):
 @pytest.mark.gpu
 def test_config4_bn254_256_columns_2_20_rows(gpu_backend, oracle):
     """configs[3] at its full shape on one GPU: 256 columns x 2^20 rows of 252-bit scalars
-    (8 GiB, torch device generator: 2^33 draws of a serial mt19937 would take minutes); every
-    one of the 256 commitments is checked"""
+    (8 GiB: the mt19937{0} stream of multi_commitment/benchmark.m.cc:141-156, column-major, produced
+    on all host threads by tools/mt19937); every one of the 256 commitments is checked"""
     import torch
     n, columns = 1 << 20, 256
-    g = torch.Generator(device="cuda:0")
-    g.manual_seed(4)
-    scalars = torch.randint(0, 256, (columns, n, 32), dtype=torch.uint8, device="cuda:0",
-                            generator=g)
-    scalars[:, :, 31] &= 0x0f
+    scalars = torch.from_numpy(wl.mt19937_scalars(columns, n, 32, top_mask=0x0f)).to("cuda:0")
     got, want = _variable_base_dlog(gpu_backend, oracle, 2, n, scalars)
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert bad.size == 0, f"columns {bad.tolist()} differ"
@@ -132,9 +128,7 @@ def test_config5_grumpkin_packed_1024_outputs_2_18_rows(gpu_backend, oracle):
     bit_table = wl.config5_bit_table(outputs)
     row_bytes = (int(bit_table.sum()) + 7) // 8
     assert row_bytes == 12618
-    g = torch.Generator(device=dev)
-    g.manual_seed(5)
-    scalars = torch.randint(0, 256, (n, row_bytes), dtype=torch.uint8, device=dev, generator=g)
+    scalars = torch.from_numpy(wl.mt19937_bytes(n * row_bytes).reshape(n, row_bytes)).to(dev)
     offs = (np.concatenate([[0], np.cumsum(bit_table)[:-1]]) // 8).astype(np.int64)
     wide = torch.from_numpy(offs[bit_table == 256] + 31).to(dev)
     scalars[:, wide] &= 0x0f  # 256-bit fields below the group order

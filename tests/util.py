@@ -40,6 +40,49 @@ def weierstrass_generators(curve_id, n, distinct_seeds=64):
     return out
 
 
+def weierstrass_generators_big(curve_id, n, distinct_seeds=1024, threads=None):
+    """the same recipe as weierstrass_generators (and the same bytes), for sets of 2^18 .. 2^22
+    points: the chain runs inside the oracle library (ref_<curve>_generator_chain), cut into
+    segments on host threads -- segment j starts at g_{k-1} + (j L) g_0, formed with the reference's
+    own double / add; affine coordinates do not depend on how a point was reached"""
+    import concurrent.futures
+    import os
+    _, nl, stride, _ = ref_oracle.CURVES[curve_id]
+    out = np.zeros((n, stride), dtype=np.uint8)
+    k = min(n, distinct_seeds)
+    for i in range(k):
+        out[i] = ref_oracle.random_affine(curve_id, i + 1, i + 2)
+    if n > k:
+        one = ref_oracle.identity_affine(curve_id)[8 * nl:16 * nl].view(np.uint64)
+
+        def p2(a):
+            return np.concatenate([a[:16 * nl].view(np.uint64), one])
+        g0, last = p2(out[0]), p2(out[k - 1])
+
+        def multiple(m):  # m * g0, m >= 1
+            acc = None
+            for bit in bin(m)[2:]:
+                if acc is not None:
+                    acc = ref_oracle.double_projective(curve_id, acc)
+                if bit == "1":
+                    acc = g0 if acc is None else ref_oracle.add_projective(curve_id, acc, g0)
+            return acc
+        threads = threads or min(32, os.cpu_count() or 1)
+        rest = n - k
+        seg = (rest + threads - 1) // threads
+        jobs = []
+        for j in range(0, rest, seg):
+            start = last if j == 0 else ref_oracle.add_projective(curve_id, last, multiple(j))
+            jobs.append((k + j, start, min(seg, rest - j)))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as ex:
+            for (at, _, count), (piece, _) in zip(jobs, ex.map(
+                    lambda job: ref_oracle.generator_chain(curve_id, job[1], g0, job[2]), jobs)):
+                out[at:at + count] = piece
+    if n > 5:
+        out[5] = ref_oracle.identity_affine(curve_id)
+    return out
+
+
 def generators_for(curve_id, n):
     if curve_id == 0:
         return ref_oracle.ristretto_generators(n)

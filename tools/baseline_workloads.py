@@ -5,14 +5,16 @@ imports nothing from oracle/).
 
   * byte streams: `std::mt19937{0}` through libstdc++'s uniform_int_distribution<uint8_t>
     (benchmark/multi_commitment/benchmark.m.cc:141-156): Lemire's method on a 32-bit engine keeps
-    the top 8 bits of every draw.  numpy's legacy MT19937 is the same engine, so the stream is
-    reproduced exactly for configs 1-3 (2^21 .. 2^27 draws, <= 4 s).  Configs 4 and 5 need 2^33 and
-    3.3e9 draws -- 215 s / 83 s of a serial generator -- and use torch's device generator instead
-    (stated in the bench line).
-  * generator sets with known discrete logarithms for the three Weierstrass curves:
-    g_i = (i + 1) G with G = the reference's generate_random_element(rng{1, 2}) (the "distinct
-    multiples" recipe of SURVEY 8(d) config 3), built on the device by
-    bzamd_generator_multiples_device.  Then  sum_i a_i g_i = (sum_i a_i (i + 1) mod r) G, one
+    the top 8 bits of every draw.  numpy's legacy MT19937 is the same engine (2^21 .. 2^27 draws for
+    configs 1-3: <= 4 s).  Configs 4 and 5 need 2^33 and 3.3e9 draws of that ONE serial stream (215 s
+    / 83 s through numpy): tools/mt19937/mtstream.cc produces the same bytes on all host threads at
+    once, thread j starting from the generator state after j L draws (polynomial jump-ahead), and
+    is used whenever it has been built (__graft_entry__.build()).
+  * generator sets for the three Weierstrass curves: SURVEY 8(d)'s recipe, g_0 = the reference's
+    generate_random_element(rng{1, 2}), g_i = g_{i-1} + g_0, built by the reference's own code on
+    host threads (reference_generators; round 3 built the same points with the product's
+    bzamd_generator_multiples_device, which is now only cross-checked against them).  The set is
+    g_i = (i + 1) g_0, so  sum_i a_i g_i = (sum_i a_i (i + 1) mod r) g_0, one
     scalar multiplication with the reference's own curve operations: a full-size parity check of
     EVERY output that costs milliseconds per output.
 """
@@ -28,8 +30,35 @@ ORDER = {
 }
 
 
-def mt19937_bytes(count, seed=0, boolean=False):
-    """`count` draws of uniform_int_distribution<uint8_t>{0, 255} (or {0, 1}) on std::mt19937{seed}"""
+_MTSTREAM = None
+
+
+def mtstream_lib():
+    """tools/mt19937/_build/libmtstream.so (None when it has not been built)"""
+    global _MTSTREAM
+    if _MTSTREAM is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mt19937", "_build",
+                            "libmtstream.so")
+        _MTSTREAM = False
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            lib.mt19937_fill.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                         ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint]
+            lib.mt19937_fill.restype = ctypes.c_int
+            _MTSTREAM = lib
+    return _MTSTREAM or None
+
+
+def mt19937_bytes(count, seed=0, boolean=False, skip=0, threads=0, force_numpy=False):
+    """draws [skip, skip + count) of uniform_int_distribution<uint8_t>{0, 255} (or {0, 1}) on
+    std::mt19937{seed}"""
+    lib = None if force_numpy else mtstream_lib()
+    if lib is not None:
+        out = np.empty(count, dtype=np.uint8)
+        lib.mt19937_fill(out.ctypes.data, count, seed, skip, threads, 31 if boolean else 24)
+        return out
+    assert skip == 0, "a stream offset needs tools/mt19937 (python __graft_entry__.py)"
     bg = np.random.MT19937()
     bg._legacy_seeding(seed)
     out = np.empty(count, dtype=np.uint8)
@@ -41,11 +70,13 @@ def mt19937_bytes(count, seed=0, boolean=False):
     return out
 
 
-def mt19937_scalars(columns, n, nbytes, top_mask=0xff, seed=0):
+def mt19937_scalars(columns, n, nbytes, top_mask=0xff, seed=0, first_column=0):
     """[columns, n, nbytes] little-endian scalars, column-major fill of one stream (column c occupies
     bytes [c n nbytes, (c + 1) n nbytes), multi_commitment/benchmark.m.cc:141-156); the top byte of
-    every scalar is masked with `top_mask` (0x0f: uniform 252-bit values)"""
-    s = mt19937_bytes(columns * n * nbytes, seed).reshape(columns, n, nbytes)
+    every scalar is masked with `top_mask` (0x0f: uniform 252-bit values).  `first_column`: the
+    columns [first_column, first_column + columns) of that stream (a rank's shard)"""
+    s = mt19937_bytes(columns * n * nbytes, seed,
+                      skip=first_column * n * nbytes).reshape(columns, n, nbytes)
     if top_mask != 0xff:
         s[:, :, nbytes - 1] &= top_mask
     return s
@@ -55,16 +86,53 @@ def vp(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def dlog_generators(lib, oracle, cid, n, dev, stream):
-    """(base affine bytes, device tensor [n, stride]) with generators[i] = (i + 1) * base"""
+def dlog_generators(lib, oracle, cid, n, dev, stream, check_device_kernel=True):
+    """(base affine bytes, device tensor [n, stride]) with generators[i] = (i + 1) * base: SURVEY
+    8(d)'s recipe (g_0 = generate_random_element(rng{1, 2}), g_i = g_{i-1} + g_0), built on the host
+    by the reference's own code (reference_generators) and uploaded.  The product's own generator
+    kernel (bzamd_generator_multiples_device, a convenience for callers without the reference) must
+    produce the same bytes: checked here at full size."""
     import torch
     from blitzar_amd import api
-    base = oracle.random_affine(cid, 1, 2)
-    d_base = torch.from_numpy(base.copy()).to(dev)
-    gens = torch.empty((n, api.CURVE_LAYOUT[cid][0]), dtype=torch.uint8, device=dev)
-    lib.bzamd_generator_multiples_device(cid, vp(gens), vp(d_base), n, stream)
+    base, host = reference_generators(oracle, cid, n)
+    gens = torch.from_numpy(host).to(dev)
+    if check_device_kernel:
+        d_base = torch.from_numpy(base.copy()).to(dev)
+        mine = torch.empty((n, api.CURVE_LAYOUT[cid][0]), dtype=torch.uint8, device=dev)
+        lib.bzamd_generator_multiples_device(cid, vp(mine), vp(d_base), n, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(mine, gens), "bzamd_generator_multiples_device differs from the reference chain"
+        del mine
     torch.cuda.synchronize()
     return base, gens
+
+
+def reference_generators(oracle, cid, n, threads=None):
+    """SURVEY 8(d)'s generator recipe for configs 3-5, built by the REFERENCE's own code (oracle/_ref:
+    generate_random_element, add, to_element_affine): g_0 = generate_random_element(rng{1, 2}),
+    g_i = g_{i-1} + g_0.  Returns (g_0 affine bytes, host array [n, stride] in C-ABI layout); the set
+    is g_i = (i + 1) g_0, so every commitment still has a closed form.  The chain runs inside the
+    oracle library on host threads, segment j starting from (j L) g_0 formed by doubling."""
+    import concurrent.futures
+    import os
+    _, nl, stride, _ = oracle.CURVES[cid]
+    base = oracle.random_affine(cid, 1, 2)
+    g0 = oracle.affine_to_projective(cid, base)[0]
+    out = np.zeros((n, stride), dtype=np.uint8)
+    out[0] = base
+    threads = threads or min(64, os.cpu_count() or 1)
+    rest = n - 1
+    if rest > 0:
+        seg = (rest + threads - 1) // threads
+        jobs = []
+        for j in range(0, rest, seg):
+            # the segment's elements are g_{1 + j}, ...: start = (1 + j) g_0
+            jobs.append((1 + j, scalar_multiple(oracle, cid, g0, 1 + j), min(seg, rest - j)))
+        with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as ex:
+            for (at, _, count), (piece, _) in zip(jobs, ex.map(
+                    lambda job: oracle.generator_chain(cid, job[1], g0, job[2]), jobs)):
+                out[at:at + count] = piece
+    return base, out
 
 
 def weighted_byte_sums(rows_u8, first_row=0, chunk_rows=1 << 14):
