@@ -414,14 +414,103 @@ __device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig
   }
 }
 
+// chunks an oversized group of `total` records is cut into in pass 2 (0: one workgroup sorts it)
+constexpr u32 kStreamedSortRecords = 16 * kLocalSortCapacity;
+__device__ __forceinline__ u32 big_chunks_of(u32 total) {
+  return total <= kStreamedSortRecords ? 0 : (total + kLocalSortCapacity - 1) / kLocalSortCapacity;
+}
+
+// Pass 1b, one workgroup of T threads per task: exclusive scans over the groups.
+//   group_start[task.group_base + g] = first record of group g, entry [G] = records of the task;
+//   group_cursor (the totals, in place) = the same offsets, bumped by k_group_scatter;
+//   group_chunk[task.group_base + g] = chunks of the oversized groups before g, entry [G] = their
+//   number (all zero on uniform digits); the bucket counters of oversized groups are cleared and
+//   the task is appended to big_tasks (big_tasks[0] = their count, zeroed by the recode kernel).
+// The totals are read with agent-scope loads: in the fused form (below) they were written by
+// atomics of other workgroups of the SAME launch.
+template <u32 T>
+__device__ __forceinline__ void
+group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ group_cursor,
+                    u32* __restrict__ group_start, u32* __restrict__ group_chunk,
+                    u32* __restrict__ bucket_count, u32* __restrict__ bucket_fill,
+                    u32* __restrict__ big_tasks, u32* wave_sums, u32* wave_chunks) {
+  constexpr u32 kWaves = T / 64;
+  const u32 groups = task.num_groups;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  u32* cur = group_cursor + task.group_base;
+  u32* gs = group_start + task.group_base;
+  u32* gc = group_chunk + task.group_base;
+  u32 carry = 0, chunk_carry = 0;
+  for (u32 g0 = 0; g0 < groups; g0 += T) {
+    const u32 g = g0 + tid;
+    const u32 total =
+        g < groups ? __hip_atomic_load(&cur[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const u32 chunks = g < groups ? big_chunks_of(total) : 0;
+    u32 incl = total, chunk_incl = chunks;
+#pragma unroll
+    for (u32 off = 1; off < 64; off <<= 1) {
+      const u32 up = __shfl_up(incl, off, 64);
+      const u32 chunk_up = __shfl_up(chunk_incl, off, 64);
+      if (lane >= off) {
+        incl += up;
+        chunk_incl += chunk_up;
+      }
+    }
+    __syncthreads(); // the sums of the previous round have been read
+    if (lane == 63) {
+      wave_sums[wave] = incl;
+      wave_chunks[wave] = chunk_incl;
+    }
+    __syncthreads();
+    u32 base = carry, chunk_base = chunk_carry;
+    u32 round_sum = 0, round_chunks = 0;
+    for (u32 w = 0; w < kWaves; ++w) {
+      if (w < wave) {
+        base += wave_sums[w];
+        chunk_base += wave_chunks[w];
+      }
+      round_sum += wave_sums[w];
+      round_chunks += wave_chunks[w];
+    }
+    if (g < groups) {
+      gs[g] = base + incl - total;
+      cur[g] = base + incl - total;
+      gc[g] = chunk_base + chunk_incl - chunks;
+      if (chunks != 0) {
+        // an oversized group: its chunks meet in these counters (k_group_big_hist / _sort)
+        const u64 first = task.bucket_base + (static_cast<u64>(g) << task.group_bits);
+        for (u32 b = 0; b < (1u << task.group_bits); ++b) {
+          bucket_count[first + b] = 0;
+          bucket_fill[first + b] = 0;
+        }
+      }
+    }
+    carry += round_sum;
+    chunk_carry += round_chunks;
+  }
+  if (tid == 0) {
+    gs[groups] = carry;
+    gc[groups] = chunk_carry;
+    // big_tasks[0] = number of tasks with oversized groups, then their indices
+    if (chunk_carry != 0) big_tasks[1 + atomicAdd(&big_tasks[0], 1u)] = task_index;
+  }
+}
+
 // Pass 1a.  group_total[task.group_base + g] += digits of the slice whose bucket lies in group g
 // (2^s consecutive buckets): LDS histogram, one global atomic per populated group.
+// `arrivals` != nullptr: the fused form -- the workgroup that finishes LAST on a task (a ticket per
+// task, zeroed with the group cursors by the recode kernel) goes on to run pass 1b for it, so
+// k_group_offsets and its ~5 us of a 17-workgroup launch disappear from the call.
 static __global__ void __launch_bounds__(kSortThreads)
     k_group_hist(u32* __restrict__ group_total, u32* __restrict__ big_tasks,
-                 const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
+                 const i16* __restrict__ digits, const task_desc* __restrict__ tasks,
+                 u32* __restrict__ arrivals, u32* __restrict__ group_start,
+                 u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
+                 u32* __restrict__ bucket_fill) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  // the list k_group_offsets appends to starts empty
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) big_tasks[0] = 0;
+  __shared__ u32 wave_sums[kSortThreads / 64];
+  __shared__ u32 wave_chunks[kSortThreads / 64];
+  __shared__ u32 last_flag;
   const task_desc task = tasks[blockIdx.y];
   const u32 slice = blockIdx.x;
   if (slice >= task.num_slices) return;
@@ -441,20 +530,20 @@ static __global__ void __launch_bounds__(kSortThreads)
   for (u32 g = tid; g < groups; g += kSortThreads) {
     if (lds[g] != 0) atomicAdd(&out[g], lds[g]);
   }
+  if (arrivals == nullptr) return;
+  __threadfence(); // this lane's atomics are performed device-wide before the ticket is taken
+  __syncthreads();
+  if (tid == 0) {
+    const u32 ticket = atomicAdd(&arrivals[blockIdx.y], 1u);
+    last_flag = ticket + 1 == task.num_slices ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_flag == 0) return;
+  __threadfence();
+  group_offsets_block<kSortThreads>(task, blockIdx.y, group_total, group_start, group_chunk,
+                                    bucket_count, bucket_fill, big_tasks, wave_sums, wave_chunks);
 }
 
-// chunks an oversized group of `total` records is cut into in pass 2 (0: one workgroup sorts it)
-constexpr u32 kStreamedSortRecords = 16 * kLocalSortCapacity;
-__device__ __forceinline__ u32 big_chunks_of(u32 total) {
-  return total <= kStreamedSortRecords ? 0 : (total + kLocalSortCapacity - 1) / kLocalSortCapacity;
-}
-
-// Pass 1b, one workgroup per task: exclusive scans over the groups.
-//   group_start[task.group_base + g] = first record of group g, entry [G] = records of the task;
-//   group_cursor (the totals, in place) = the same offsets, bumped by k_group_scatter;
-//   group_chunk[task.group_base + g] = chunks of the oversized groups before g, entry [G] = their
-//   number (all zero on uniform digits); the bucket counters of oversized groups are cleared and
-//   the task is appended to big_tasks.
 static __global__ void __launch_bounds__(256)
     k_group_offsets(u32* __restrict__ group_cursor, u32* __restrict__ group_start,
                     u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
@@ -463,59 +552,8 @@ static __global__ void __launch_bounds__(256)
   __shared__ u32 wave_sums[4];
   __shared__ u32 wave_chunks[4];
   const task_desc task = tasks[blockIdx.x];
-  const u32 groups = task.num_groups;
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  u32* cur = group_cursor + task.group_base;
-  u32* gs = group_start + task.group_base;
-  u32* gc = group_chunk + task.group_base;
-  u32 carry = 0, chunk_carry = 0;
-  for (u32 g0 = 0; g0 < groups; g0 += 256) {
-    const u32 g = g0 + tid;
-    const u32 total = g < groups ? cur[g] : 0;
-    const u32 chunks = g < groups ? big_chunks_of(total) : 0;
-    u32 incl = total, chunk_incl = chunks;
-#pragma unroll
-    for (u32 off = 1; off < 64; off <<= 1) {
-      const u32 up = __shfl_up(incl, off, 64);
-      const u32 chunk_up = __shfl_up(chunk_incl, off, 64);
-      if (lane >= off) {
-        incl += up;
-        chunk_incl += chunk_up;
-      }
-    }
-    __syncthreads(); // the sums of the previous round have been read
-    if (lane == 63) {
-      wave_sums[wave] = incl;
-      wave_chunks[wave] = chunk_incl;
-    }
-    __syncthreads();
-    u32 base = carry, chunk_base = chunk_carry;
-    for (u32 w = 0; w < wave; ++w) {
-      base += wave_sums[w];
-      chunk_base += wave_chunks[w];
-    }
-    if (g < groups) {
-      gs[g] = base + incl - total;
-      cur[g] = base + incl - total;
-      gc[g] = chunk_base + chunk_incl - chunks;
-      if (chunks != 0) {
-        // an oversized group: its chunks meet in these counters (k_group_big_hist / _sort)
-        const u64 first = task.bucket_base + (static_cast<u64>(g) << task.group_bits);
-        for (u32 b = 0; b < (1u << task.group_bits); ++b) {
-          bucket_count[first + b] = 0;
-          bucket_fill[first + b] = 0;
-        }
-      }
-    }
-    carry += wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
-    chunk_carry += wave_chunks[0] + wave_chunks[1] + wave_chunks[2] + wave_chunks[3];
-  }
-  if (tid == 0) {
-    gs[groups] = carry;
-    gc[groups] = chunk_carry;
-    // big_tasks[0] = number of tasks with oversized groups (zeroed by the host), then their indices
-    if (chunk_carry != 0) big_tasks[1 + atomicAdd(&big_tasks[0], 1u)] = blockIdx.x;
-  }
+  group_offsets_block<256>(task, blockIdx.x, group_cursor, group_start, group_chunk, bucket_count,
+                           bucket_fill, big_tasks, wave_sums, wave_chunks);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
@@ -543,10 +581,14 @@ __device__ __forceinline__ void unpack_digits(const uint4& pack, int e[8]) {
 // variant (more than kMaxStagedGroups groups: columns beyond ~2^25 rows) stores records one by
 // one.  Per vector the eight cursor bumps are issued before the eight dependent stores.
 //   dynamic LDS: Staged ? 3 * groups + 1 + kStagedSliceRows : groups   words
-template <bool Staged>
+// RankOnce (Staged only: every digit vector of the slice is held in registers): the counting pass
+// keeps what its atomic returns -- the digit's rank inside its group -- and the second pass places
+// the record at local_start[group] + rank with a plain LDS read instead of a second atomic.
+template <bool Staged, bool RankOnce = false>
 __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_scatter(u32* __restrict__ records, u32* __restrict__ group_cursor,
                     const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
+  static_assert(Staged || !RankOnce);
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   __shared__ u32 wave_sums[kSortThreads / 64];
   const task_desc task = tasks[blockIdx.y];
@@ -572,13 +614,29 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   auto vector_at = [&](u32 v) {
     return v == tid ? held[0] : (v == tid + kSortThreads ? held[1] : dig4[v]);
   };
-  for (u32 v = tid; v < nvec; v += kSortThreads) {
-    int e[8];
-    unpack_digits(vector_at(v), e);
+  u32 rank[2][8];
+  if constexpr (RankOnce) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u32 mag = e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k]);
-      if (v * 8 + k < rows && e[k] != 0) atomicAdd(&cursor[(mag - 1) >> s], 1u);
+    for (int j = 0; j < 2; ++j) {
+      const u32 v = tid + static_cast<u32>(j) * kSortThreads;
+      int e[8];
+      unpack_digits(held[j], e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 mag = e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k]);
+        rank[j][k] = 0;
+        if (v * 8 + k < rows && e[k] != 0) rank[j][k] = atomicAdd(&cursor[(mag - 1) >> s], 1u);
+      }
+    }
+  } else {
+    for (u32 v = tid; v < nvec; v += kSortThreads) {
+      int e[8];
+      unpack_digits(vector_at(v), e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 mag = e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k]);
+        if (v * 8 + k < rows && e[k] != 0) atomicAdd(&cursor[(mag - 1) >> s], 1u);
+      }
     }
   }
   lds_barrier();
@@ -611,28 +669,51 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   lds_barrier();
   u32* out = records + task.entry_base;
   const u32 in_group = (1u << s) - 1, shift = 31 - s;
-  for (u32 v = tid; v < nvec; v += kSortThreads) {
-    int e[8];
-    unpack_digits(vector_at(v), e);
-    u32 pos[8], rec[8];
-    bool take[8];
+  if constexpr (RankOnce) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      // E = -D: positive E means the digit is negative -> subtract the generator
-      const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
-      take[k] = v * 8 + k < rows && e[k] != 0;
-      rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
-               (static_cast<u32>(row0) + v * 8 + k);
-      pos[k] = 0;
-      if (take[k]) pos[k] = atomicAdd(&cursor[bucket >> s], 1u);
+    for (int j = 0; j < 2; ++j) {
+      const u32 v = tid + static_cast<u32>(j) * kSortThreads;
+      int e[8];
+      unpack_digits(held[j], e);
+      u32 pos[8], rec[8];
+      bool take[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
+        take[k] = v * 8 + k < rows && e[k] != 0;
+        rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
+                 (static_cast<u32>(row0) + v * 8 + k);
+        pos[k] = take[k] ? local_start[bucket >> s] + rank[j][k] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (take[k]) staging[pos[k]] = rec[k];
+      }
     }
+  } else {
+    for (u32 v = tid; v < nvec; v += kSortThreads) {
+      int e[8];
+      unpack_digits(vector_at(v), e);
+      u32 pos[8], rec[8];
+      bool take[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (take[k]) {
-        if constexpr (Staged) {
-          staging[pos[k]] = rec[k];
-        } else {
-          out[pos[k]] = rec[k];
+      for (int k = 0; k < 8; ++k) {
+        // E = -D: positive E means the digit is negative -> subtract the generator
+        const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
+        take[k] = v * 8 + k < rows && e[k] != 0;
+        rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
+                 (static_cast<u32>(row0) + v * 8 + k);
+        pos[k] = 0;
+        if (take[k]) pos[k] = atomicAdd(&cursor[bucket >> s], 1u);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (take[k]) {
+          if constexpr (Staged) {
+            staging[pos[k]] = rec[k];
+          } else {
+            out[pos[k]] = rec[k];
+          }
         }
       }
     }
@@ -666,22 +747,36 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
 // on skewed data all 64 lanes hit the same counter, which would serialise them.
 constexpr u32 kGroupSortThreads = 512;
 constexpr u32 kLocalSortPerThread = kLocalSortCapacity / kGroupSortThreads;
-constexpr u32 kBigSortBlocks = 128; // grid of the two oversized-group launches (their workgroups
-                                    // loop; even empty ones cost ~35 ns each to dispatch)
+constexpr u32 kBigSortBlocks = 128; // workgroups that share the chunks of the oversized groups
+                                    // (they loop; even empty ones cost ~35 ns each to dispatch)
 static_assert(kLocalSortPerThread * kGroupSortThreads == kLocalSortCapacity);
 static_assert(2 * kGroupSortThreads >= (1u << kMaxGroupBits));
 
+// LDS of the pass-2 kernels.  `run_base` / `local_start` are used by the oversized-group path only.
+struct sort_lds {
+  u32 cursor[1u << kMaxGroupBits];
+  u32 staging[kLocalSortCapacity];
+  u32 wave_sums[kGroupSortThreads / 64];
+};
+struct big_sort_lds {
+  u32 run_base[1u << kMaxGroupBits];    // where this chunk's run of the bucket goes (group-relative)
+  u32 local_start[1u << kMaxGroupBits]; // first staged entry of the bucket
+};
+
+// RankOnce: the counting pass keeps the rank its atomic returns, the placing pass adds the bucket's
+// start with a plain LDS read (one LDS atomic per record instead of two).
+template <bool RankOnce>
 __device__ __forceinline__ void
 group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
                  u32* __restrict__ segment_bucket, u32* __restrict__ bucket_end,
                  const u32* __restrict__ records, const u32* __restrict__ group_start,
-                 const u32* __restrict__ group_chunk) {
-  __shared__ u32 cursor[1u << kMaxGroupBits];
-  __shared__ u32 staging[kLocalSortCapacity];
-  __shared__ u32 wave_sums[kGroupSortThreads / 64];
+                 const u32* __restrict__ group_chunk, sort_lds& lds) {
+  u32* cursor = lds.cursor;
+  u32* staging = lds.staging;
+  u32* wave_sums = lds.wave_sums;
   if (g >= task.num_groups) return;
   const u32* gc = group_chunk + task.group_base;
-  if (gc[g + 1] != gc[g]) return; // oversized: k_group_big_hist / k_group_big_sort
+  if (gc[g + 1] != gc[g]) return; // oversized: the chunked path
   const u32 s = task.group_bits, buckets = 1u << s;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32* gs = group_start + task.group_base;
@@ -692,6 +787,7 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
   const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
   const bool staged = total <= kLocalSortCapacity; // uniform over the workgroup
   u32 mine[kLocalSortPerThread];
+  u32 pos[kLocalSortPerThread];
   if (staged) {
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
@@ -700,7 +796,14 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
     }
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      if (tid + k * kGroupSortThreads < total) atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+      pos[k] = 0;
+      if (tid + k * kGroupSortThreads < total) {
+        if constexpr (RankOnce) {
+          pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        } else {
+          atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        }
+      }
     }
   } else {
     // up to kStreamedSortRecords records (a window whose digits use few of its buckets): streamed
@@ -748,13 +851,15 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
   u32* out = sorted + task.entry_base + begin;
   u32* seg = segment_bucket + task.segment_base;
   const u32 seg_log2 = task.segment_log2, seg_mask = (1u << seg_log2) - 1;
-  u32 pos[kLocalSortPerThread];
   if (staged) {
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      pos[k] = 0;
       if (tid + k * kGroupSortThreads < total) {
-        pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        if constexpr (RankOnce) {
+          pos[k] += cursor[(mine[k] >> shift) & in_group];
+        } else {
+          pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        }
       }
     }
 #pragma unroll
@@ -793,16 +898,6 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
       }
     }
   }
-}
-
-static __global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                 u32* __restrict__ bucket_end, const u32* __restrict__ records,
-                 const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                 const task_desc* __restrict__ tasks) {
-  const task_desc task = tasks[blockIdx.y];
-  group_sort_block(blockIdx.x, task, sorted, segment_bucket, bucket_end, records, group_start,
-                   group_chunk);
 }
 
 // The oversized group that chunk `index` (counted over all oversized groups of the task) belongs
@@ -849,12 +944,13 @@ __device__ __forceinline__ u32 wave_aggregated_add(u32* counters, u32 key, bool 
   return result;
 }
 
-static __global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_big_hist(u32* __restrict__ bucket_count, const u32* __restrict__ records,
-                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
-  __shared__ u32 cursor[1u << kMaxGroupBits];
-  const u32 num_big_tasks = big_tasks[0];
+// Oversized groups, phase 1: worker `worker` of `workers` adds the bucket histograms of its chunks
+// (of every listed task) into bucket_count.
+__device__ __forceinline__ void
+big_hist_body(u32 worker, u32 workers, u32* __restrict__ bucket_count,
+              const u32* __restrict__ records, const u32* __restrict__ group_start,
+              const u32* __restrict__ group_chunk, const task_desc* __restrict__ tasks,
+              const u32* __restrict__ big_tasks, u32 num_big_tasks, u32* cursor) {
   for (u32 t = 0; t < num_big_tasks; ++t) {
     const task_desc task = tasks[big_tasks[1 + t]];
     const u32* gc = group_chunk + task.group_base;
@@ -863,8 +959,8 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
     const u32 tid = threadIdx.x;
     const u32 in_group = buckets - 1, shift = 31 - s;
     const u32* gs = group_start + task.group_base;
-    // every workgroup of the launch takes chunks of every listed task, starting at a different one
-    for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
+    // every worker takes chunks of every listed task, starting at a different one
+    for (u32 index = (worker + 5 * t) % workers; index < big_chunks; index += workers) {
       const u32 g = locate_big_group(gc, task.num_groups, index);
       const u32 begin = gs[g] + (index - gc[g]) * kLocalSortCapacity;
       const u32 left = gs[g + 1] - begin;
@@ -893,20 +989,21 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
   }
 }
 
-static __global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_big_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                     u32* __restrict__ bucket_end, const u32* __restrict__ bucket_count,
-                     u32* __restrict__ bucket_fill, const u32* __restrict__ records,
-                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
-  constexpr u32 kBuckets = 1u << kMaxGroupBits;
-  __shared__ u32 run_base[kBuckets];    // where this chunk's run of the bucket goes (group-relative)
-  __shared__ u32 local_start[kBuckets]; // first staged entry of the bucket
-  __shared__ u32 cursor[kBuckets];
-  __shared__ u32 staging[kLocalSortCapacity];
-  __shared__ unsigned short staged_bucket[kLocalSortCapacity];
-  __shared__ u32 wave_sums[kGroupSortThreads / 64];
-  const u32 num_big_tasks = big_tasks[0];
+// Oversized groups, phase 2 (all of phase 1 is complete and visible): scan the group's bucket
+// counts, claim a run per (chunk, bucket) with an atomic on bucket_fill, sort the chunk in LDS and
+// copy the runs out.  The staged records keep their bucket bits until they are copied out.
+__device__ __forceinline__ void
+big_sort_body(u32 worker, u32 workers, u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+              u32* __restrict__ bucket_end, const u32* __restrict__ bucket_count,
+              u32* __restrict__ bucket_fill, const u32* __restrict__ records,
+              const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+              const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks,
+              u32 num_big_tasks, sort_lds& lds, big_sort_lds& big) {
+  u32* cursor = lds.cursor;
+  u32* staging = lds.staging;
+  u32* wave_sums = lds.wave_sums;
+  u32* run_base = big.run_base;
+  u32* local_start = big.local_start;
   for (u32 t = 0; t < num_big_tasks; ++t) {
     const task_desc task = tasks[big_tasks[1 + t]];
     const u32* gc = group_chunk + task.group_base;
@@ -932,7 +1029,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       for (u32 w = 0; w < wave; ++w) start0 += wave_sums[w];
       start1 = start0 + v0;
     };
-    for (u32 index = (blockIdx.x + 5 * t) % gridDim.x; index < big_chunks; index += gridDim.x) {
+    for (u32 index = (worker + 5 * t) % workers; index < big_chunks; index += workers) {
       const u32 g = locate_big_group(gc, task.num_groups, index);
       const u32 chunk = index - gc[g];
       const u32 group_begin = gs[g], group_end = gs[g + 1];
@@ -946,9 +1043,15 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
         const u32 i = tid + k * kGroupSortThreads;
         mine[k] = i < total ? rec[i] : 0;
       }
-      // the group's bucket starts from the global histogram
+      // the group's bucket starts from the global histogram (written by atomics of other
+      // workgroups, possibly of this very launch: agent-scope loads)
       const u32* counts = bucket_count + task.bucket_base + (static_cast<u64>(g) << s);
-      const u32 g0 = b0 < buckets ? counts[b0] : 0, g1 = b0 + 1 < buckets ? counts[b0 + 1] : 0;
+      const u32 g0 = b0 < buckets ? __hip_atomic_load(&counts[b0], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : 0;
+      const u32 g1 = b0 + 1 < buckets ? __hip_atomic_load(&counts[b0 + 1], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0;
       u32 gstart0, gstart1;
       scan_pairs(g0, g1, gstart0, gstart1);
       if (chunk == 0) {
@@ -985,19 +1088,17 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
         const bool active = tid + k * kGroupSortThreads < total;
         const u32 b = (mine[k] >> shift) & in_group;
         const u32 pos = wave_aggregated_add(cursor, b, active);
-        if (active) {
-          staging[pos] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
-          staged_bucket[pos] = static_cast<unsigned short>(b);
-        }
+        if (active) staging[pos] = mine[k];
       }
       lds_barrier();
       u32* out = sorted + task.entry_base + group_begin;
       u32* seg = segment_bucket + task.segment_base;
       const u32 seg_log2 = task.segment_log2, seg_mask = (1u << seg_log2) - 1;
       for (u32 i = tid; i < total; i += kGroupSortThreads) {
-        const u32 b = staged_bucket[i];
+        const u32 r = staging[i];
+        const u32 b = (r >> shift) & in_group;
         const u32 at = run_base[b] + (i - local_start[b]); // group-relative position
-        out[at] = staging[i];
+        out[at] = (r & 0x80000000u) | (r & row_mask);
         if (((group_begin + at) & seg_mask) == 0) {
           seg[(group_begin + at) >> seg_log2] = (g << s) + b;
         }
@@ -1005,6 +1106,84 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
       lds_barrier(); // the LDS arrays are reused by the next chunk
     }
   }
+}
+
+template <bool RankOnce>
+__global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                 u32* __restrict__ bucket_end, const u32* __restrict__ records,
+                 const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                 const task_desc* __restrict__ tasks) {
+  __shared__ sort_lds lds;
+  const task_desc task = tasks[blockIdx.y];
+  group_sort_block<RankOnce>(blockIdx.x, task, sorted, segment_bucket, bucket_end, records,
+                             group_start, group_chunk, lds);
+}
+
+static __global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_big_hist(u32* __restrict__ bucket_count, const u32* __restrict__ records,
+                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
+  __shared__ u32 cursor[1u << kMaxGroupBits];
+  big_hist_body(blockIdx.x, gridDim.x, bucket_count, records, group_start, group_chunk, tasks,
+                big_tasks, big_tasks[0], cursor);
+}
+
+static __global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_big_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                     u32* __restrict__ bucket_end, const u32* __restrict__ bucket_count,
+                     u32* __restrict__ bucket_fill, const u32* __restrict__ records,
+                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
+  __shared__ sort_lds lds;
+  __shared__ big_sort_lds big;
+  big_sort_body(blockIdx.x, gridDim.x, sorted, segment_bucket, bucket_end, bucket_count,
+                bucket_fill, records, group_start, group_chunk, tasks, big_tasks, big_tasks[0], lds,
+                big);
+}
+
+// Pass 2 with the oversized groups inside the same launch: one more row of the grid
+// (blockIdx.y == num_tasks), whose first kBigSortBlocks workgroups are the workers of the chunked
+// path.  They return at once when no task has an oversized group (uniform digits: big_tasks[0] was
+// settled by pass 1b) -- the two extra launches of the separate kernels, ~9 us per call, are gone.
+// Otherwise phase 1 and phase 2 are separated by a barrier among the workers (a counter in global
+// memory, zeroed by the recode kernel): at most 128 workgroups of 512 threads and 36 KiB of LDS,
+// which the machine holds at once whatever else of this launch is resident, and every other
+// workgroup of the launch terminates on its own, so all workers get dispatched.
+template <bool RankOnce>
+__global__ void __launch_bounds__(kGroupSortThreads)
+    k_group_sort_all(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                     u32* __restrict__ bucket_end, const u32* __restrict__ records,
+                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
+                     const task_desc* __restrict__ tasks, u32 num_tasks,
+                     u32* __restrict__ bucket_count, u32* __restrict__ bucket_fill,
+                     const u32* __restrict__ big_tasks, u32* __restrict__ big_barrier) {
+  __shared__ sort_lds lds;
+  if (blockIdx.y < num_tasks) {
+    const task_desc task = tasks[blockIdx.y];
+    group_sort_block<RankOnce>(blockIdx.x, task, sorted, segment_bucket, bucket_end, records,
+                               group_start, group_chunk, lds);
+    return;
+  }
+  __shared__ big_sort_lds big;
+  const u32 workers = gridDim.x < kBigSortBlocks ? gridDim.x : kBigSortBlocks;
+  if (blockIdx.x >= workers) return;
+  const u32 num_big_tasks = big_tasks[0];
+  if (num_big_tasks == 0) return;
+  big_hist_body(blockIdx.x, workers, bucket_count, records, group_start, group_chunk, tasks,
+                big_tasks, num_big_tasks, lds.cursor);
+  __threadfence(); // this lane's histogram atomics are performed device-wide
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(big_barrier, 1u);
+    while (__hip_atomic_load(big_barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < workers) {
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  __syncthreads();
+  __threadfence();
+  big_sort_body(blockIdx.x, workers, sorted, segment_bucket, bucket_end, bucket_count, bucket_fill,
+                records, group_start, group_chunk, tasks, big_tasks, num_big_tasks, lds, big);
 }
 
 //--------------------------------------------------------------------------------------------------
