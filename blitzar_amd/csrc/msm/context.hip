@@ -63,6 +63,13 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_DEDICATED_QUEUES", ctx->dedicated_queues);
   flag("BLITZAR_AMD_FAST_RECODE", ctx->fast_recode);
   flag("BLITZAR_AMD_TAIL_LOW_PRIORITY", ctx->tail_low_priority);
+  flag("BLITZAR_AMD_FUSE_OFFSETS", ctx->fuse_offsets);
+  if (const char* v = std::getenv("BLITZAR_AMD_FUSE_BIG")) {
+    const unsigned long m = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(m <= 2, "BLITZAR_AMD_FUSE_BIG must be 0, 1 or 2");
+    ctx->fuse_big = static_cast<u32>(m);
+  }
+  flag("BLITZAR_AMD_RANK_ONCE", ctx->rank_once);
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");

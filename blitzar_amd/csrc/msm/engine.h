@@ -195,6 +195,13 @@ struct msm_context {
   // streams are blocking streams, hence never for a caller on the NULL stream.
   bool dedicated_queues = true; // BLITZAR_AMD_DEDICATED_QUEUES=0: plain non-blocking streams
   bool fast_recode = true;      // BLITZAR_AMD_FAST_RECODE=0: the generic recode kernel for every shape
+  // the front of a call in fewer launches / LDS atomics (round 4; "=0": the separate kernels of
+  // round 3, kept for A/B runs):
+  bool fuse_offsets = true; // BLITZAR_AMD_FUSE_OFFSETS: pass 1b inside k_group_hist (last workgroup per task)
+  // BLITZAR_AMD_FUSE_BIG: the oversized-group path inside k_group_sort's launch -- 0: two launches
+  // of its own, 1: its histogram phase, 2: both phases (a barrier among its workers in between)
+  u32 fuse_big = 2;
+  bool rank_once = true;    // BLITZAR_AMD_RANK_ONCE: one LDS atomic per record in scatter and sort
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
     hipStream_t s = nullptr;
     if (mask != nullptr || dedicated_queues) {
@@ -334,9 +341,11 @@ static void configure_sort_kernels(msm_context& ctx) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_hist),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true>),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false>),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   ctx.kernels_configured = true;
 }
@@ -349,6 +358,14 @@ struct pipe_mode {
   u32 end_sets() const { return split ? 3 : (piped ? 2 : 1); }
   u32 tail_sets() const { return piped ? 2 : 1; }
 };
+
+// The block of words the recode kernel clears for the sort of the same batch, one allocation:
+//   group cursors [total_groups + 1] | arrival tickets of k_group_hist [num_tasks] | barrier of the
+//   oversized-group workers [1] | big_tasks: count [1] + task list [num_tasks]
+// (`zero_words` = everything up to and including the count)
+static inline size_t zeroed_block_words(u64 total_groups, size_t num_tasks) {
+  return static_cast<size_t>(total_groups) + 1 + num_tasks + 1 + 1 + num_tasks;
+}
 
 // device workspace of one batch of columns (everything carved from the arena)
 template <class C>
@@ -363,8 +380,8 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   if (needs_addends) front += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
   front += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
   front += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
-  front += 3 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
-  front += device_arena::padded(sizeof(u32) * (num_tasks + 1));
+  front += 2 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
+  front += device_arena::padded(sizeof(u32) * zeroed_block_words(plan.total_groups, num_tasks));
   front += device_arena::padded(sizeof(u32) * 2 * (plan.total_buckets + 1));
   front += device_arena::padded(sizeof(u32) * (plan.total_segments + 1));
   const size_t ends = device_arena::padded(sizeof(u32) * (plan.total_buckets + 1));
@@ -495,6 +512,8 @@ template <class C> struct batch_buffers {
   u32* records;
   u32* sorted;
   u32* group_cursor;
+  u32* arrivals;    // tickets of k_group_hist's workgroups, per task
+  u32* big_barrier; // arrival counter of the oversized-group workers
   u32* group_start;
   u32* group_chunk;
   u32* big_tasks;    // [0] = count, then the tasks that have oversized groups
@@ -617,10 +636,12 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     i16* digits = ctx.arena.take<i16>(plan.total_entries + 8);
     u32* records = ctx.arena.take<u32>(plan.total_entries + 8);
     u32* sorted = ctx.arena.take<u32>(plan.total_entries + 8);
-    u32* group_cursor = ctx.arena.take<u32>(plan.total_groups + 1);
+    u32* group_cursor = ctx.arena.take<u32>(zeroed_block_words(plan.total_groups, num_tasks));
     u32* group_start = ctx.arena.take<u32>(plan.total_groups + 1);
     u32* group_chunk = ctx.arena.take<u32>(plan.total_groups + 1);
-    u32* big_tasks = ctx.arena.take<u32>(num_tasks + 1);
+    u32* arrivals = group_cursor + plan.total_groups + 1;
+    u32* big_barrier = arrivals + num_tasks;
+    u32* big_tasks = big_barrier + 1;
     u32* bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
     u32* segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
     if (set == (mode.split ? parity : 0)) {
@@ -629,6 +650,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       b.records = records;
       b.sorted = sorted;
       b.group_cursor = group_cursor;
+      b.arrivals = arrivals;
+      b.big_barrier = big_barrier;
       b.group_start = group_start;
       b.group_chunk = group_chunk;
       b.big_tasks = big_tasks;
@@ -674,7 +697,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
     });
   }
-  const u64 zero_words = plan.total_groups + 1; // group cursors, cleared by the recode kernel
+  // group cursors, arrival tickets, the workers' barrier, big_tasks[0]: cleared by the recode kernel
+  const u64 zero_words = plan.total_groups + 1 + num_tasks + 2;
   // the common shape has a recode kernel of its own: byte-aligned unsigned 32-byte scalars,
   // 16-bit windows, one task per window (grid.y = columns)
   bool rows32_c16 = num_cols <= 65535;
@@ -706,34 +730,79 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, fs, b.digits, b.cols,
                        b.tasks, num_cols, chunks, b.group_cursor, zero_words);
   });
+  u32 sort_launches = 0;
   ctx.timer.timed(timing, 2, fs, [&] {
-    hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks);
     u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
-    hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, fs, b.group_cursor,
-                       b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
-                       b.tasks);
+    // pass 1a (+ 1b in the last workgroup of every task)
+    hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
+                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks,
+                       ctx.fuse_offsets ? b.arrivals : static_cast<u32*>(nullptr), b.group_start,
+                       b.group_chunk, b.bucket_count, bucket_fill);
+    sort_launches += 1;
+    if (!ctx.fuse_offsets) {
+      hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, fs, b.group_cursor,
+                         b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
+                         b.tasks);
+      sort_launches += 1;
+    }
     // all tasks of a launch share one variant: staged unless some column needs the direct form
     if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
       const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
-      hipLaunchKernelGGL(k_group_scatter<true>, dim3(plan.max_task_slices, num_tasks),
-                         dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
-                         b.tasks);
+      if (ctx.rank_once) {
+        hipLaunchKernelGGL((k_group_scatter<true, true>), dim3(plan.max_task_slices, num_tasks),
+                           dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
+                           b.tasks);
+      } else {
+        hipLaunchKernelGGL((k_group_scatter<true, false>), dim3(plan.max_task_slices, num_tasks),
+                           dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
+                           b.tasks);
+      }
     } else {
-      hipLaunchKernelGGL(k_group_scatter<false>, dim3(plan.max_task_slices, num_tasks),
+      hipLaunchKernelGGL((k_group_scatter<false, false>), dim3(plan.max_task_slices, num_tasks),
                          dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
-    hipLaunchKernelGGL(k_group_sort, dim3(plan.max_task_groups, num_tasks), dim3(kGroupSortThreads),
-                       0, fs, b.sorted, b.segment_bucket, b.bucket_end, b.records, b.group_start,
-                       b.group_chunk, b.tasks);
-    // oversized groups (skewed digits); both launches find nothing to do on uniform data
-    hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
-                       b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,
-                       b.big_tasks);
-    hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
-                       b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
-                       b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
+    sort_launches += 1;
+    // pass 2; oversized groups (skewed digits) in the same launch or in two launches of their own
+    // -- either way they find nothing to do on uniform data
+    if (ctx.fuse_big != 0) {
+      const dim3 grid(plan.max_task_groups, num_tasks + 1);
+      auto launch_all = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(kGroupSortThreads), 0, fs, b.sorted, b.segment_bucket,
+                           b.bucket_end, b.records, b.group_start, b.group_chunk, b.tasks,
+                           num_tasks, b.bucket_count, bucket_fill, b.big_tasks, b.big_barrier);
+      };
+      if (ctx.fuse_big == 2) {
+        ctx.rank_once ? launch_all(k_group_sort_all<true, true>)
+                      : launch_all(k_group_sort_all<false, true>);
+      } else {
+        ctx.rank_once ? launch_all(k_group_sort_all<true, false>)
+                      : launch_all(k_group_sort_all<false, false>);
+        hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
+                           b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
+                           b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
+        sort_launches += 1;
+      }
+      sort_launches += 1;
+    } else {
+      const dim3 grid(plan.max_task_groups, num_tasks);
+      if (ctx.rank_once) {
+        hipLaunchKernelGGL((k_group_sort<true>), grid, dim3(kGroupSortThreads), 0, fs, b.sorted,
+                           b.segment_bucket, b.bucket_end, b.records, b.group_start, b.group_chunk,
+                           b.tasks);
+      } else {
+        hipLaunchKernelGGL((k_group_sort<false>), grid, dim3(kGroupSortThreads), 0, fs, b.sorted,
+                           b.segment_bucket, b.bucket_end, b.records, b.group_start, b.group_chunk,
+                           b.tasks);
+      }
+      hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
+                         b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,
+                         b.big_tasks);
+      hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
+                         b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
+                         b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
+      sort_launches += 3;
+    }
   });
   if (mode.split) ctx.front_done[k & 3].record(fs);
 
@@ -772,7 +841,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     ctx.join_two_back(stream, k);
   }
   if (timing) ctx.timer.calls += 1;
-  g_kernel_launches += 10;
+  g_kernel_launches += 5 + sort_launches; // (prepare), recode, the sort, accumulate, reduce, horner
   BZ_HIP_CHECK(hipGetLastError());
 }
 

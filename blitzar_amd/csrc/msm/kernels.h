@@ -501,7 +501,7 @@ group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ gro
 // `arrivals` != nullptr: the fused form -- the workgroup that finishes LAST on a task (a ticket per
 // task, zeroed with the group cursors by the recode kernel) goes on to run pass 1b for it, so
 // k_group_offsets and its ~5 us of a 17-workgroup launch disappear from the call.
-static __global__ void __launch_bounds__(kSortThreads)
+static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_hist(u32* __restrict__ group_total, u32* __restrict__ big_tasks,
                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks,
                  u32* __restrict__ arrivals, u32* __restrict__ group_start,
@@ -787,7 +787,8 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
   const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
   const bool staged = total <= kLocalSortCapacity; // uniform over the workgroup
   u32 mine[kLocalSortPerThread];
-  u32 pos[kLocalSortPerThread];
+  // RankOnce: ranks inside the bucket (< kLocalSortCapacity < 2^16), two per register
+  u32 rank2[(kLocalSortPerThread + 1) / 2];
   if (staged) {
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
@@ -796,11 +797,18 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
     }
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      pos[k] = 0;
-      if (tid + k * kGroupSortThreads < total) {
-        if constexpr (RankOnce) {
-          pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+      if constexpr (RankOnce) {
+        u32 r = 0;
+        if (tid + k * kGroupSortThreads < total) {
+          r = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+        }
+        if ((k & 1) == 0) {
+          rank2[k / 2] = r;
         } else {
+          rank2[k / 2] |= r << 16;
+        }
+      } else {
+        if (tid + k * kGroupSortThreads < total) {
           atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
         }
       }
@@ -852,22 +860,25 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
   u32* seg = segment_bucket + task.segment_base;
   const u32 seg_log2 = task.segment_log2, seg_mask = (1u << seg_log2) - 1;
   if (staged) {
+    u32 at[kLocalSortPerThread];
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+      at[k] = 0;
       if (tid + k * kGroupSortThreads < total) {
+        const u32 b = (mine[k] >> shift) & in_group;
         if constexpr (RankOnce) {
-          pos[k] += cursor[(mine[k] >> shift) & in_group];
+          at[k] = cursor[b] + ((rank2[k / 2] >> (16 * (k & 1))) & 0xffffu);
         } else {
-          pos[k] = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+          at[k] = atomicAdd(&cursor[b], 1u);
         }
       }
     }
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
       if (tid + k * kGroupSortThreads < total) {
-        staging[pos[k]] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
-        if (((begin + pos[k]) & seg_mask) == 0) {
-          seg[(begin + pos[k]) >> seg_log2] = (g << s) + ((mine[k] >> shift) & in_group);
+        staging[at[k]] = (mine[k] & 0x80000000u) | (mine[k] & row_mask);
+        if (((begin + at[k]) & seg_mask) == 0) {
+          seg[(begin + at[k]) >> seg_log2] = (g << s) + ((mine[k] >> shift) & in_group);
         }
       }
     }
@@ -875,6 +886,7 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
     for (u32 i = tid; i < total; i += kGroupSortThreads) out[i] = staging[i];
   } else {
     for (u32 base = 0; base < total; base += kLocalSortCapacity) {
+      u32 pos[kLocalSortPerThread];
 #pragma unroll
       for (u32 k = 0; k < kLocalSortPerThread; ++k) {
         const u32 i = base + tid + k * kGroupSortThreads;
@@ -1109,7 +1121,7 @@ big_sort_body(u32 worker, u32 workers, u32* __restrict__ sorted, u32* __restrict
 }
 
 template <bool RankOnce>
-__global__ void __launch_bounds__(kGroupSortThreads)
+__global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: four workgroups per CU
     k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
                  u32* __restrict__ bucket_end, const u32* __restrict__ records,
                  const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
@@ -1145,13 +1157,16 @@ static __global__ void __launch_bounds__(kGroupSortThreads)
 // Pass 2 with the oversized groups inside the same launch: one more row of the grid
 // (blockIdx.y == num_tasks), whose first kBigSortBlocks workgroups are the workers of the chunked
 // path.  They return at once when no task has an oversized group (uniform digits: big_tasks[0] was
-// settled by pass 1b) -- the two extra launches of the separate kernels, ~9 us per call, are gone.
-// Otherwise phase 1 and phase 2 are separated by a barrier among the workers (a counter in global
-// memory, zeroed by the recode kernel): at most 128 workgroups of 512 threads and 36 KiB of LDS,
-// which the machine holds at once whatever else of this launch is resident, and every other
-// workgroup of the launch terminates on its own, so all workers get dispatched.
-template <bool RankOnce>
-__global__ void __launch_bounds__(kGroupSortThreads)
+// settled by pass 1b), and an empty launch of a separate kernel, ~4.5 us, is gone from the call.
+//   BigSortToo = false: phase 1 (the histograms) only; k_group_big_sort stays a launch of its own;
+//   BigSortToo = true: both phases, separated by a barrier among the workers (a counter in global
+//     memory, zeroed by the recode kernel): at most 128 workgroups of 512 threads and 36 KiB of LDS,
+//     which the machine holds at once whatever else of this launch is resident, and every other
+//     workgroup of the launch terminates on its own, so all workers get dispatched.  Phase 2 needs
+//     ~100 VGPRs; inside this kernel's budget of 64 (four workgroups per CU for pass 2 proper) it
+//     spills a little, on the skewed path only.
+template <bool RankOnce, bool BigSortToo>
+__global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: four workgroups per CU
     k_group_sort_all(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
                      u32* __restrict__ bucket_end, const u32* __restrict__ records,
                      const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
@@ -1165,25 +1180,28 @@ __global__ void __launch_bounds__(kGroupSortThreads)
                                group_start, group_chunk, lds);
     return;
   }
-  __shared__ big_sort_lds big;
   const u32 workers = gridDim.x < kBigSortBlocks ? gridDim.x : kBigSortBlocks;
   if (blockIdx.x >= workers) return;
   const u32 num_big_tasks = big_tasks[0];
   if (num_big_tasks == 0) return;
   big_hist_body(blockIdx.x, workers, bucket_count, records, group_start, group_chunk, tasks,
                 big_tasks, num_big_tasks, lds.cursor);
-  __threadfence(); // this lane's histogram atomics are performed device-wide
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(big_barrier, 1u);
-    while (__hip_atomic_load(big_barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < workers) {
-      __builtin_amdgcn_s_sleep(16);
+  if constexpr (BigSortToo) {
+    __shared__ big_sort_lds big;
+    __threadfence(); // this lane's histogram atomics are performed device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(big_barrier, 1u);
+      while (__hip_atomic_load(big_barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < workers) {
+        __builtin_amdgcn_s_sleep(16);
+      }
     }
+    __syncthreads();
+    __threadfence();
+    big_sort_body(blockIdx.x, workers, sorted, segment_bucket, bucket_end, bucket_count,
+                  bucket_fill, records, group_start, group_chunk, tasks, big_tasks, num_big_tasks,
+                  lds, big);
   }
-  __syncthreads();
-  __threadfence();
-  big_sort_body(blockIdx.x, workers, sorted, segment_bucket, bucket_end, bucket_count, bucket_fill,
-                records, group_start, group_chunk, tasks, big_tasks, num_big_tasks, lds, big);
 }
 
 //--------------------------------------------------------------------------------------------------
@@ -1419,7 +1437,14 @@ __global__ void __launch_bounds__(kReduceThreads)
   // entries of the task, for k_horner (which then reads nothing a following sort overwrites)
   if (blockIdx.x == 0 && tid == 0) task_total[blockIdx.y] = total;
   point* dst = partials + static_cast<u64>(blockIdx.y) * partial_stride + blockIdx.x;
-  if (total == 0) {
+  // a block none of whose buckets holds an entry (the upper blocks of a top window whose digits
+  // use few of its buckets, the carry window): the identity, without the scan and the tree -- at
+  // 252-bit scalars in 16-bit windows that is 30 of a column's 272 blocks, which otherwise share
+  // compute units with blocks that have work
+  const u32 block_end = block_first + (kReduceThreads << lane_log2) < nb
+                            ? block_first + (kReduceThreads << lane_log2)
+                            : nb;
+  if (total == 0 || ends[block_end - 1] == (block_first == 0 ? 0 : ends[block_first - 1])) {
     if (tid == 0) *dst = C::identity();
     return;
   }
