@@ -155,6 +155,25 @@ def timed_calls(lib, fn, steps, warmup, stream):
     return dt, stages
 
 
+def lone_calls(fn, calls=3):
+    """ms of a lone call with plain stream semantics (no throughput mode): each call is followed by
+    a device synchronisation; the minimum and the mean over `calls` calls after one untimed call"""
+    fn()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0))
+    return {"min": min(ms), "mean": sum(ms) / len(ms), "calls": calls}
+
+
+STAGE_NOTE = ("stage times of calls IN A SEQUENCE: HIP-event spans on the stream each stage runs on; "
+              "the tail stages (reduce, combine) of a call run beside the next call at the lowest "
+              "queue priority, so the spans overlap and do NOT add up to ms_per_call")
+
+
 def profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -271,6 +290,7 @@ def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps,
 
     dt, stages = timed_calls(lib, step, steps, 1, stream)
     got = out.cpu().numpy()
+    lone = lone_calls(step)
     bad = []
     for c in range(columns):
         sums = wl.weighted_byte_sums(scalars[c])
@@ -282,8 +302,10 @@ def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps,
     stride = api.CURVE_LAYOUT[cid][0]
     alg_bytes = ops * 32 + n * stride + columns * api.CURVE_LAYOUT[cid][1]
     entry = {"config": name, "rows": n, "columns": columns, "ms_per_call": dt * 1e3,
+             "lone_call_ms": round(lone["min"], 4), "lone_call_ms_mean": round(lone["mean"], 4),
              "scalar_point_ops_per_s": ops / dt, "commitments_per_s": columns / dt,
              "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
+             "stage_ms_note": STAGE_NOTE,
              "verified": f"all {columns} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
                          "encoded by the reference's curve code",
              # one bucket addition per non-zero digit: 252-bit scalars populate 16 windows of 16 bits
@@ -332,6 +354,7 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
 
     dt, stages = timed_calls(lib, step, steps, 1, stream)
     got = res.cpu().numpy()
+    lone = lone_calls(step)
     sums = wl.weighted_byte_sums(scalars)
     bad = []
     for k in range(outputs):
@@ -347,12 +370,14 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
     entry = {"config": f"5: grumpkin packed fixed-base, {outputs} outputs x 2^{log2n} rows, "
                        "8/32/256-bit fields", "rows": n, "outputs": outputs,
              "bits_per_row": int(bit_table.sum()), "ms_per_call": dt * 1e3,
+             "lone_call_ms": round(lone["min"], 4), "lone_call_ms_mean": round(lone["mean"], 4),
              "row_output_ops_per_s": ops / dt, "outputs_per_s": outputs / dt,
              "handle_creation_s": handle_s,
              "data": "mt19937{0} bytes (tools/mt19937: the one serial stream produced on all host "
                      "threads by jump-ahead), the 256-bit fields masked to 252 bits; generators: "
                      "SURVEY 8(d)'s chain g_i = g_{i-1} + g_0 built by the reference's own code",
              "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
+             "stage_ms_note": STAGE_NOTE,
              "verified": f"all {outputs} outputs bit-exact vs (sum a_i (i+1) mod r) G computed and "
                          "encoded by the reference's curve code",
              # bucket additions: one per signed 16-bit window of every field (1 / 3 / 16 for 8 / 32 /
@@ -495,6 +520,44 @@ def in_process_multi_device():
         return {"error": repr(exc)[:300]}
 
 
+def host_api():
+    """What a drop-in caller sees: the blocking sxt_* entry points with HOST buffers, PCIe-inclusive,
+    in child processes (their own sxt_init, no torch): the native warm driver
+    (tools/pipeline_bench/hostapi_bench.cc) and the clone of the reference's own benchmark CLI
+    (tools/multi_commitment: `multi_commitment gpu 1048576 10 {1,10} 32`, whose mean includes the
+    first, cold sample -- benchmark/multi_commitment/benchmark.m.cc:204-236).  Never `value`."""
+    import subprocess
+    out = {"what": "sxt_curve25519_compute_pedersen_commitments[_with_generators], host buffers, "
+                   "2^20 rows x 32 bytes per column; every call uploads its scalars (and the caller's "
+                   "160-byte generators) over PCIe and blocks until the commitments are in host memory"}
+    exe = os.path.join(ROOT, "tools", "pipeline_bench", "_build", "hostapi_bench")
+    try:
+        r = subprocess.run([exe, "--samples", "10", "--warmup", "2"], capture_output=True, text=True,
+                           timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out["warm"] = json.loads(lines[-1]) if lines else {"error": f"rc {r.returncode}",
+                                                           "stderr_tail": r.stderr[-400:]}
+    except Exception as exc:  # a failure here must not cost the bench line
+        out["warm"] = {"error": repr(exc)[:300]}
+    cli = os.path.join(ROOT, "tools", "multi_commitment", "_build", "multi_commitment")
+    out["reference_cli_clone"] = []
+    for columns in (1, 10):
+        entry = {"command": f"multi_commitment gpu 1048576 10 {columns} 32 0"}
+        try:
+            r = subprocess.run([cli, "gpu", "1048576", "10", str(columns), "32", "0"],
+                               capture_output=True, text=True, timeout=300)
+            for ln in r.stdout.splitlines():
+                if ln.startswith("compute duration (s)"):
+                    entry["mean_ms_incl_cold_first_sample"] = 1e3 * float(ln.split(":")[1])
+                if ln.startswith("throughput (exponentiations / s)"):
+                    entry["exponentiations_per_s"] = float(ln.split(":")[1])
+            entry["rc"] = r.returncode
+        except Exception as exc:
+            entry["error"] = repr(exc)[:300]
+        out["reference_cli_clone"].append(entry)
+    return out
+
+
 #--------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -607,6 +670,8 @@ def main():
         lib.bzamd_pipeline_flush(stream)
         torch.cuda.synchronize()
         legs["resident_ms"] = 1e3 * (time.perf_counter() - t1) / resident_steps
+        legs["untimed_calls_before_clock"] = (legs.get("untimed_calls_before_clock", 0)
+                                              + max(args.warmup, 2) + resident_steps)
         legs["resident_acc"], _ = clock2.collect(resident_steps)
         legs["resident_output"] = out2.cpu().numpy().copy()
 
@@ -631,6 +696,7 @@ def main():
         torch.cuda.synchronize()
         legs["sustained_ms"] = begin.elapsed_time(end) / calls
         legs["sustained_calls"] = calls
+        legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 2 + 30 + calls
 
     # Order.  The device idles at ~100 MHz and comes back slowly: after ANY idle gap (20 ms are
     # enough) the first calls of a sequence take 1.14, 1.11, 1.06, 1.03, 1.00, 0.98 ms ... and the
@@ -743,6 +809,10 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            # calls of the timed shape (and of the resident-generators shape) issued right before
+            # the W warmup steps to get the device out of its idle clocks (see "Order" above): the
+            # timed region is a SUSTAINED-clock figure
+            "effective_warmup_calls": legs["untimed_calls_before_clock"] + args.warmup,
             "ms_per_step": ms_per_step,
             "single_call_ms": single_call_ms,
             "sustained_ms_per_step": legs["sustained_ms"],
@@ -814,6 +884,8 @@ def main():
         # the 570 MB librccl for that costs up to a minute on a fresh box)
         if not args.no_configs and not args.dry_run_one_gpu and torch.cuda.device_count() > 1:
             result["in_process_multi_device"] = in_process_multi_device()
+        if world == 1 and not args.no_configs and args.log2n is None:
+            result["host_api"] = host_api()
         print(json.dumps(result), flush=True)
 
 

@@ -57,7 +57,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-I" + ROOT,
 MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 TU_FLAGS = {
     "msm/msm_curve25519.hip": MAX_ILP,
-    "msm/msm_curve25519_accumulate.hip": ["-DBZ_ACC_WAVES_ED=2"],
+    "msm/msm_curve25519_accumulate.hip": ["-DBZ_ACCUMULATE_WAVES_OVERRIDE=2"],
     "msm/msm_curve25519_niels_accumulate.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
     "msm/msm_bls12_381_accumulate.hip": MAX_ILP,
     "msm/msm_bn254_accumulate.hip": MAX_ILP,

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +46,12 @@ api_state* g_state = nullptr;
 api_state& state() {
   BZ_RELEASE_ASSERT(g_state != nullptr, "backend not initialised (call sxt_init first)");
   return *g_state;
+}
+
+// devices[0] of the GPU backend (where single-device helpers stage their data); nothing to hold on
+// the host backend
+api_state::device_lease lease_primary(api_state& st) {
+  return st.backend == SXT_GPU_BACKEND ? st.lease(st.primary()) : api_state::device_lease{};
 }
 
 // built-in generators: raw p3 copies on the host (served by sxt_ristretto255_get_generators, feed
@@ -319,11 +327,22 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   return d_out;
 }
 
-// the Pedersen path of all five entry points; the caller holds st.api_mutex
+// does a call with these columns spread over all devices of the GPU backend?
+bool shards_over_devices(const api_state& st, const checked_columns& cc) {
+  size_t scalar_bytes = 0;
+  for (const auto& c : cc.cols) scalar_bytes += static_cast<size_t>(c.n) * c.row_stride;
+  return st.devices.size() > 1 && scalar_bytes >= g_shard_min_bytes.load() && cc.longest > 0;
+}
+
+// The Pedersen path of all five entry points.  GPU backend: the caller holds the lease of `single`
+// (the call stays on that device) or, with `single` == nullptr, of every device (the call may
+// shard).  Sequences of more than one pass fold their partials on devices[0]: `single` must be that
+// device then (compute_commitments sees to it).
 void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* commitments,
                                 u32 num_sequences, const sxt_sequence_descriptor* descriptors,
                                 const void* generators, generator_source source,
-                                u64 offset_generators, bool projective_out) {
+                                u64 offset_generators, bool projective_out,
+                                device_state* single) {
   checked_columns cc = check_descriptors(descriptors, num_sequences);
   const u32 out_stride = static_cast<u32>(projective_out ? vt.projective_size : vt.output_size);
 
@@ -381,14 +400,14 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
   //     over xGMI (hipMemcpyPeerAsync, <= 160 B per column and device), device 0 folds and encodes
   //     (k_fold_encode).  Group addition is exact, so the canonical result is the same.
   const size_t num_devices = st.devices.size();
-  const bool shard = num_devices > 1 && scalar_bytes >= g_shard_min_bytes.load() && cc.longest > 0;
+  const bool shard = single == nullptr && shards_over_devices(st, cc);
   const generator_ref all_gens{source, generators, offset_generators};
   // sequences longer than one pass of the engine: row ranges, like the row split below
   const u64 max_rows = g_max_rows_per_pass.load();
   const size_t passes = static_cast<size_t>((cc.longest + max_rows - 1) / max_rows);
 
   if (!shard && passes <= 1) {
-    device_state& ds = st.primary();
+    device_state& ds = single != nullptr ? *single : st.primary();
     std::vector<hipEvent_t> events;
     u8* d_out = enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
                                     projective_out, events);
@@ -486,9 +505,23 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
   if (num_sequences == 0) return; // reference: returns before touching anything
   BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
   api_state& st = state();
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
-  compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
-                             offset_generators, projective_out);
+  if (st.backend != SXT_GPU_BACKEND) { // the host backend keeps no per-call state: no lock
+    compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
+                               offset_generators, projective_out, nullptr);
+    return;
+  }
+  // which devices the call needs is a function of its shapes alone
+  const checked_columns cc = check_descriptors(descriptors, num_sequences);
+  const bool several_passes = cc.longest > g_max_rows_per_pass.load();
+  if (shards_over_devices(st, cc)) {
+    api_state::device_lease lease = st.lease_all();
+    compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
+                               offset_generators, projective_out, nullptr);
+  } else {
+    api_state::device_lease lease = several_passes ? st.lease(st.primary()) : st.lease_any();
+    compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
+                               offset_generators, projective_out, lease.device);
+  }
 }
 
 int backend_from_environment(int backend) {
@@ -516,8 +549,10 @@ void commit_column_unlocked(api_state& st, u8* out32, const u8* scalars, u64 n,
   d.n = n;
   d.data = scalars;
   d.is_signed = 0;
+  // (the proof entry points hold the lease of devices[0])
   compute_commitments_locked(st, curve25519_vtable(), out32, 1, &d, generators,
-                             generator_source::host_api, 0, false);
+                             generator_source::host_api, 0, false,
+                             st.backend == SXT_GPU_BACKEND ? &st.primary() : nullptr);
 }
 } // namespace proof
 } // namespace bz
@@ -635,7 +670,7 @@ int sxt_ristretto255_get_generators(struct sxt_ristretto255* generators, uint64_
   api_state& st = state();
   if (num_generators == 0) return 0;
   if (generators == nullptr) return 1;
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const api_state::device_lease lease = lease_primary(st);
   host_builtin_generators(st, reinterpret_cast<ed_point*>(generators), num_generators,
                           offset_generators);
   return 0;
@@ -644,7 +679,7 @@ int sxt_ristretto255_get_generators(struct sxt_ristretto255* generators, uint64_
 int sxt_curve25519_get_one_commit(struct sxt_ristretto255* one_commit, uint64_t n) {
   api_state& st = state();
   BZ_RELEASE_ASSERT(one_commit != nullptr, "one_commit is null");
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const api_state::device_lease lease = lease_primary(st);
   ed_point r;
   if (n < st.host_one_commits.size()) {
     r = st.host_one_commits[n];
@@ -681,10 +716,10 @@ unsigned partition_window_width() {
 void handle_make_resident(multiexp_handle& h) {
   api_state& st = state();
   if (st.backend != SXT_GPU_BACKEND || h.n == 0) return;
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
   const size_t bytes = h.vt->projective_size * h.n;
   for (auto& dsp : st.devices) {
     device_state& ds = *dsp;
+    const api_state::device_lease lease = st.lease(ds);
     ds.activate();
     void* d_proj = nullptr;
     BZ_HIP_CHECK(hipMalloc(&d_proj, bytes));
@@ -744,7 +779,6 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
       max_len = std::max(max_len, piece_lengths[i]);
     }
     if (bit_table != nullptr && record) {
-      std::lock_guard<std::mutex> api_lock(st.api_mutex);
       recorder = std::make_unique<dump_recorder>(lengths != nullptr ? "vlen-multiexponentiation"
                                                                      : "packed-multiexponentiation");
       if (recorder->recording()) {
@@ -806,7 +840,6 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
                        cols, table->d_addends, caller_stream, table->tables());
     return;
   }
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
 
   // BLITZAR_DUMP_DIR: record packed / vlen calls with host operands (the plain byte-aligned entry
   // point is not recorded by the reference either, gpu_backend.cc:257-272)
@@ -835,6 +868,9 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   std::vector<unit_range> ranges{{0, num_outputs}};
   if (shard) ranges = split_by_weight(column_weights(cols), num_devices);
   u8* out = static_cast<u8*>(res);
+  // GPU backend: every device for a sharded call, else the first one nobody holds
+  api_state::device_lease lease;
+  if (st.backend == SXT_GPU_BACKEND) lease = shard ? st.lease_all() : st.lease_any();
 
   if (st.backend == SXT_CPU_BACKEND) {
     run_on_devices(ranges.size(), [&](size_t k) {
@@ -855,7 +891,7 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   run_on_devices(ranges.size(), [&](size_t k) {
     const unit_range r = ranges[k];
     if (r.begin == r.end) return;
-    device_state& ds = *st.devices[k];
+    device_state& ds = shard ? *st.devices[k] : *lease.device;
     ds.activate();
     std::vector<host_column> mine(cols.begin() + r.begin, cols.begin() + r.end);
     u64 rows = 0;
@@ -936,7 +972,7 @@ void sxt_multiexp_handle_write_to_file(const struct sxt_multiexp_handle* handle,
   api_state& st = state();
   bool ok = false;
   if (st.backend == SXT_GPU_BACKEND && h->window_width <= 16 && h->n > 0) {
-    std::lock_guard<std::mutex> api_lock(st.api_mutex);
+    const api_state::device_lease lease = st.lease(st.primary());
     device_state& ds = st.primary();
     ds.activate();
     ok = h->vt->write_partition_table_device(f, h->window_width, h->host_projective.data(), h->n,
@@ -1028,7 +1064,7 @@ void sxt_curve25519_prove_inner_product(struct sxt_ristretto255_compressed* l_ve
                     "l_vector and r_vector must not be null when n is bigger than one");
   BZ_RELEASE_ASSERT(n <= (uint64_t{1} << 30), "inner products are limited to 2^30 elements");
   api_state& st = state();
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const api_state::device_lease lease = lease_primary(st);
   proof::prove_inner_product(st, reinterpret_cast<u8*>(l_vector), reinterpret_cast<u8*>(r_vector),
                              ap_value->bytes, transcript, n, generators_offset,
                              reinterpret_cast<const u8*>(a_vector),
@@ -1055,7 +1091,7 @@ int sxt_curve25519_verify_inner_product(struct sxt_transcript* transcript, uint6
                     "l_vector and r_vector must not be null when n is bigger than one");
   BZ_RELEASE_ASSERT(n <= (uint64_t{1} << 30), "inner products are limited to 2^30 elements");
   api_state& st = state();
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const api_state::device_lease lease = lease_primary(st);
   return proof::verify_inner_product(st, transcript, n, generators_offset,
                                      reinterpret_cast<const u8*>(b_vector), product->bytes,
                                      a_commit, reinterpret_cast<const u8*>(l_vector),
@@ -1074,13 +1110,16 @@ void sxt_prove_sumcheck(void* polynomials, void* evaluation_point, unsigned fiel
                         descriptor->product_terms != nullptr,
                     "null table in the sumcheck descriptor");
   api_state& st = state();
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  // devices[0] is held while the prover works on it and given up around every call of the caller's
+  // transcript callback, which may therefore call back into this library (the tables of the proof
+  // live in memory of the call's own, not in the device's staging arena)
+  api_state::device_lease lease = lease_primary(st);
   const proof::sumcheck_inputs in{descriptor->mles,         descriptor->product_table,
                                   descriptor->product_terms, descriptor->n,
                                   descriptor->num_mles,      descriptor->num_products,
                                   descriptor->num_product_terms, descriptor->round_degree};
   proof::prove_sumcheck(st, polynomials, evaluation_point, field_id, in, transcript_callback,
-                        transcript_context);
+                        transcript_context, &lease);
 }
 
 //--------------------------------------------------------------------------------------------------
@@ -1118,6 +1157,10 @@ int bzamd_accumulate_form(void) {
 }
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
+
+uint32_t bzamd_concurrent_calls_high_water(void) {
+  return g_state == nullptr ? 0 : g_state->in_flight_high.load();
+}
 
 void bzamd_stage_timing_begin(uint64_t max_calls) {
   api_state& st = state();
@@ -1290,37 +1333,71 @@ void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_
   BZ_RELEASE_ASSERT(generators != nullptr, "generators is null");
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
-  std::lock_guard<std::mutex> api_lock(st.api_mutex);
+  const api_state::device_lease lease = st.lease_all();
   const size_t D = st.devices.size();
   const checked_columns cc = check_descriptors(descriptors, num_sequences);
+  // (one pass of the engine per column here: its sorted entries hold a row in 31 bits)
+  BZ_RELEASE_ASSERT(cc.longest <= g_max_rows_per_pass.load(),
+                    "bzamd_msm_multi_device: sequences longer than one engine pass are not supported");
   const u32 out_stride = static_cast<u32>(vt->output_size);
   const size_t per = (num_sequences + D - 1) / D; // columns per device (the last ones may be short)
   const size_t chunk = per * out_stride;          // bytes every device contributes
   int current = 0;
   BZ_HIP_CHECK(hipGetDevice(&current));
 
-  // the exchange: RCCL over the devices' links, unless two slots share a physical device
+  // the exchange: RCCL over the devices' links, unless two slots share a physical device (RCCL
+  // refuses duplicates) or there is only one device (nothing to exchange: librccl is never mapped).
+  // ncclCommInitAll runs on a helper thread with a deadline (BLITZAR_AMD_RCCL_INIT_TIMEOUT_S,
+  // default 60): a first-ever bring-up of the fabric that never returns must not hang the caller --
+  // the exchange falls back to peer copies and says so.
   if (st.exchange_state == 0) {
-    bool distinct = true;
+    bool distinct = D > 1;
     for (size_t a = 0; a < D; ++a) {
       for (size_t b = a + 1; b < D; ++b) distinct = distinct && st.devices[a]->device != st.devices[b]->device;
     }
     rccl_api* rccl = distinct ? rccl_api::get() : nullptr;
     st.exchange_state = 2;
     if (rccl != nullptr) {
-      std::vector<int> ids(D);
-      for (size_t d = 0; d < D; ++d) ids[d] = st.devices[d]->device;
-      std::vector<ncclComm_t> comms(D);
-      const ncclResult_t r = rccl->comm_init_all(comms.data(), static_cast<int>(D), ids.data());
-      if (r == ncclSuccess) {
-        for (auto c : comms) st.comms.push_back(c);
+      struct init_job {
+        std::vector<int> ids;
+        std::vector<ncclComm_t> comms;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t result = ncclSuccess;
+      };
+      auto job = std::make_shared<init_job>();
+      job->ids.resize(D);
+      job->comms.resize(D);
+      for (size_t d = 0; d < D; ++d) job->ids[d] = st.devices[d]->device;
+      std::thread([job, rccl] {
+        const ncclResult_t r =
+            rccl->comm_init_all(job->comms.data(), static_cast<int>(job->ids.size()), job->ids.data());
+        std::lock_guard<std::mutex> lock(job->mu);
+        job->result = r;
+        job->done = true;
+        job->cv.notify_all();
+      }).detach();
+      long deadline_s = 60;
+      if (const char* v = std::getenv("BLITZAR_AMD_RCCL_INIT_TIMEOUT_S")) {
+        const long parsed = std::strtol(v, nullptr, 10);
+        if (parsed >= 1 && parsed <= 3600) deadline_s = parsed;
+      }
+      std::unique_lock<std::mutex> lock(job->mu);
+      const bool in_time =
+          job->cv.wait_for(lock, std::chrono::seconds(deadline_s), [&] { return job->done; });
+      if (in_time && job->result == ncclSuccess) {
+        for (auto c : job->comms) st.comms.push_back(c);
         st.destroy_comm = [](void* c) {
           if (rccl_api* api = rccl_api::get()) (void)api->comm_destroy(static_cast<ncclComm_t>(c));
         };
         st.exchange_state = 1;
+      } else if (!in_time) {
+        std::fprintf(stderr, "blitzar_amd: ncclCommInitAll did not return within %ld s; using peer "
+                             "copies\n", deadline_s);
       } else {
         std::fprintf(stderr, "blitzar_amd: ncclCommInitAll failed (%s); using peer copies\n",
-                     rccl->get_error_string != nullptr ? rccl->get_error_string(r) : "?");
+                     rccl->get_error_string != nullptr ? rccl->get_error_string(job->result) : "?");
       }
     }
   }

@@ -5,9 +5,20 @@
 #pragma once
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
+
+// The six entry points used here have had the same C ABI since NCCL 2.0 (an opaque communicator
+// pointer, int-sized enums); they are declared locally so that building this library needs no RCCL
+// headers and the copy of librccl found at run time (a PyTorch process carries its own) cannot
+// disagree with a header from another install.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;   // non-zero: an error (text: ncclGetErrorString)
+typedef enum { ncclUint8 = 1 } ncclDataType_t;   // ncclChar = 0, ncclUint8 = 1 in every release
+}
 
 namespace bz {
 struct rccl_api {

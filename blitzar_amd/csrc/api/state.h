@@ -15,6 +15,7 @@
 //                             split_options (pippenger2/multiexponentiation.t.cc:150-180)
 #pragma once
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -92,6 +93,11 @@ struct resident_table {
 };
 
 struct device_state {
+  // A blocking sxt_* call owns the devices it runs on for its duration: their stream pair, engine
+  // context and staging arena (api_state::device_lease).  Calls on different devices run
+  // concurrently, like the reference's thread_local schedulers and pinned pools
+  // (sxt/execution/schedule/scheduler.cc:65-69, sxt/base/device/pinned_buffer_pool.h:52-55).
+  std::mutex mu;
   int slot = 0;   // index into api_state::devices (handles keep one addend replica per slot)
   int device = 0; // HIP device id
   hipStream_t stream = nullptr;
@@ -115,9 +121,73 @@ struct api_state {
   int backend = 0; // SXT_CPU_BACKEND / SXT_GPU_BACKEND
   // devices[0] is the device that was current at sxt_init: single-device work runs there
   std::vector<std::unique_ptr<device_state>> devices;
-  // the blocking sxt_* entry points are serialised (the reference tolerates concurrent callers
-  // only because its per-call state is thread_local; here the staging arenas are per device)
-  std::mutex api_mutex;
+  // Locking of the blocking sxt_* entry points: per device, no process-wide lock (round 3 had one).
+  //   lease_any()  a call that stays on one device takes the first device nobody holds (slot
+  //                order), or queues on them round-robin: two host threads on a two-device backend
+  //                run side by side;
+  //   lease_all()  a call that shards over the devices takes all of them, in slot order (every
+  //                multi-device holder locks in that order: no cycles);
+  //   lease(ds)    one specific device.
+  // The host backend keeps no per-call state and takes no lock at all.
+  struct device_lease {
+    std::vector<std::unique_lock<std::mutex>> held;
+    device_state* device = nullptr; // lease_any / lease: the device leased
+    api_state* owner = nullptr;
+    device_lease() = default;
+    device_lease(device_lease&&) = default;
+    device_lease& operator=(device_lease&&) = default;
+    ~device_lease() {
+      if (owner != nullptr && !held.empty()) owner->in_flight.fetch_sub(1);
+    }
+    // give the devices up for the duration of a caller-supplied callback and take them back
+    void unlock() {
+      for (auto it = held.rbegin(); it != held.rend(); ++it) it->unlock();
+    }
+    void relock() {
+      for (auto& l : held) l.lock();
+    }
+  };
+  std::atomic<u32> next_device{0};
+  std::atomic<u32> in_flight{0};        // leases alive now
+  std::atomic<u32> in_flight_high{0};   // ... and the most there ever were (tests)
+  void note_lease(device_lease& l) {
+    l.owner = this;
+    const u32 now = in_flight.fetch_add(1) + 1;
+    u32 seen = in_flight_high.load();
+    while (now > seen && !in_flight_high.compare_exchange_weak(seen, now)) {
+    }
+  }
+  device_lease lease(device_state& ds) {
+    device_lease l;
+    l.held.emplace_back(ds.mu);
+    l.device = &ds;
+    note_lease(l);
+    return l;
+  }
+  device_lease lease_any() {
+    device_lease l;
+    for (auto& d : devices) {
+      std::unique_lock<std::mutex> lock(d->mu, std::try_to_lock);
+      if (lock.owns_lock()) {
+        l.held.push_back(std::move(lock));
+        l.device = d.get();
+        note_lease(l);
+        return l;
+      }
+    }
+    device_state& ds = *devices[next_device.fetch_add(1) % devices.size()];
+    l.held.emplace_back(ds.mu);
+    l.device = &ds;
+    note_lease(l);
+    return l;
+  }
+  device_lease lease_all() {
+    device_lease l;
+    for (auto& d : devices) l.held.emplace_back(d->mu);
+    l.device = devices.empty() ? nullptr : devices[0].get();
+    note_lease(l);
+    return l;
+  }
   size_t host_shards = 1; // SXT_CPU_BACKEND: host threads a call is split over (FORCE_SHARDS)
   device_arena gather; // on devices[0]: partial results of the other devices (row-split calls)
   // RCCL communicators of bzamd_msm_multi_device (one per device slot, ncclCommInitAll on first

@@ -44,10 +44,7 @@ struct ed25519_msm {
   // addend, prefetched next addend, product temporaries)
   // (measured on MI355X at config 2: 2 / 3 / 4 waves per SIMD -> 0.862 / 0.860 / 1.13 ms, the last
   // one spills: the kernel is issue-bound, not latency-bound)
-#ifndef BZ_ACC_WAVES_ED
-#define BZ_ACC_WAVES_ED 3
-#endif
-  static constexpr int accumulate_waves_per_simd = BZ_ACC_WAVES_ED;
+  static constexpr int accumulate_waves_per_simd = 3;
   static constexpr bool has_batched_prepare = false;
 
   BZ_HD static point identity() { return ed29::identity(); }

@@ -499,7 +499,12 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   }
   // the operands have been consumed once the last front is through: the caller may overwrite
   // them in stream order
-  if (mode.split && ctx.seq != 0) ctx.front_done[(ctx.seq - 1) & 3].wait(stream);
+  // (resident addends -- generator sets, window tables, handle tables -- are read by the
+  // accumulation: a caller who frees or rewrites them in stream order must come behind that too)
+  if (mode.split && ctx.seq != 0) {
+    ctx.front_done[(ctx.seq - 1) & 3].wait(stream);
+    if (d_addends != nullptr) ctx.acc_done[(ctx.seq - 1) & 3].wait(stream);
+  }
   ctx.mark_enqueued(stream);
 }
 

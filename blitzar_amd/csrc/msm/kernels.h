@@ -531,15 +531,20 @@ static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two wo
     if (lds[g] != 0) atomicAdd(&out[g], lds[g]);
   }
   if (arrivals == nullptr) return;
-  __threadfence(); // this lane's atomics are performed device-wide before the ticket is taken
+  // No fences: the group totals are only ever touched by agent-scope atomics (performed at the
+  // device's coherence point, not in an XCD's L2) and read back with agent-scope atomic loads, and
+  // the barrier below waits until every atomic of this workgroup has been acknowledged before the
+  // ticket is taken.  (A __threadfence() per lane here is an L2 write-back + invalidate per
+  // wavefront on a part whose eight L2s are not coherent with each other: measured, it took this
+  // kernel from 11 to 600 us.)
   __syncthreads();
   if (tid == 0) {
-    const u32 ticket = atomicAdd(&arrivals[blockIdx.y], 1u);
+    const u32 ticket = __hip_atomic_fetch_add(&arrivals[blockIdx.y], 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
     last_flag = ticket + 1 == task.num_slices ? 1u : 0u;
   }
   __syncthreads();
   if (last_flag == 0) return;
-  __threadfence();
   group_offsets_block<kSortThreads>(task, blockIdx.y, group_total, group_start, group_chunk,
                                     bucket_count, bucket_fill, big_tasks, wave_sums, wave_chunks);
 }
@@ -1188,16 +1193,16 @@ __global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: four wor
                 big_tasks, num_big_tasks, lds.cursor);
   if constexpr (BigSortToo) {
     __shared__ big_sort_lds big;
-    __threadfence(); // this lane's histogram atomics are performed device-wide
+    // (the histogram counters are touched by agent-scope atomics only and read back with
+    // agent-scope loads; the barrier waits for this workgroup's atomics: no fences, see k_group_hist)
     __syncthreads();
     if (threadIdx.x == 0) {
-      atomicAdd(big_barrier, 1u);
+      __hip_atomic_fetch_add(big_barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       while (__hip_atomic_load(big_barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < workers) {
         __builtin_amdgcn_s_sleep(16);
       }
     }
     __syncthreads();
-    __threadfence();
     big_sort_body(blockIdx.x, workers, sorted, segment_bucket, bucket_end, bucket_count,
                   bucket_fill, records, group_start, group_chunk, tasks, big_tasks, num_big_tasks,
                   lds, big);
@@ -1238,8 +1243,17 @@ template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 d
 #ifndef BZ_HORNER_PRIO
 #define BZ_HORNER_PRIO 3
 #endif
+// waves per SIMD the accumulation loop is compiled for: the curve's constant, unless the translation
+// unit that INSTANTIATES the kernel overrides it (blitzar_amd/build.py: the curve25519 loop under a
+// bound of two waves keeps its 140 VGPRs but loses a third of its s_nop padding).  The override only
+// changes an attribute of the kernel's definition; every class constant is the same in every unit.
+#ifdef BZ_ACCUMULATE_WAVES_OVERRIDE
+#define BZ_ACCUMULATE_WAVES(C) (BZ_ACCUMULATE_WAVES_OVERRIDE)
+#else
+#define BZ_ACCUMULATE_WAVES(C) (C::accumulate_waves_per_simd)
+#endif
 template <class C>
-__global__ void __launch_bounds__(kAccumulateThreads, C::accumulate_waves_per_simd)
+__global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     k_accumulate(typename C::point* __restrict__ bucket_sums, typename C::point* __restrict__ heads,
                  const u32* __restrict__ bucket_end, const u32* __restrict__ segment_bucket,
                  const u32* __restrict__ sorted, const typename C::addend* __restrict__ addends,

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256)
 //--------------------------------------------------------------------------------------------------
 template <class E>
 void prove(api_state& st, u8* polynomials, u8* evaluation_point, const sumcheck_inputs& d,
-           void* callback, void* context) {
+           void* callback, void* context, api_state::device_lease* lease) {
   using F = typename E::F;
   using fe = typename F::fe;
   using callback_t = void (*)(void* r, void* context, const void* polynomial, unsigned length);
@@ -195,23 +195,24 @@ void prove(api_state& st, u8* polynomials, u8* evaluation_point, const sumcheck_
   product_desc<F>* d_products = nullptr;
   u32* d_terms = nullptr;
   device_state* ds = nullptr;
+  device_arena own; // not the device's staging arena: the lease is given up around the callback
   std::vector<fe> partials(static_cast<size_t>(kRoundBlocks) * (kMaxDegree + 1));
   if (on_device) {
     ds = &st.primary();
     ds->activate();
     const u64 half = (u64{1} << (num_variables - 1)) * d.num_mles;
-    ds->io.reset(device_arena::padded(static_cast<size_t>(E::element_bytes) * total) +
+    own.reset(device_arena::padded(static_cast<size_t>(E::element_bytes) * total) +
                      device_arena::padded(sizeof(fe) * total) + device_arena::padded(sizeof(fe) * half) +
                      device_arena::padded(sizeof(fe) * partials.size()) +
                      device_arena::padded(sizeof(product_desc<F>) * products.size()) +
                      device_arena::padded(sizeof(u32) * d.num_product_terms) + 4096,
                  ds->stream);
-    u8* d_raw = ds->io.take<u8>(static_cast<size_t>(E::element_bytes) * total);
-    d_mles = ds->io.take<fe>(total);
-    d_next = ds->io.take<fe>(half);
-    d_partials = ds->io.take<fe>(partials.size());
-    d_products = ds->io.take<product_desc<F>>(products.size());
-    d_terms = ds->io.take<u32>(d.num_product_terms);
+    u8* d_raw = own.take<u8>(static_cast<size_t>(E::element_bytes) * total);
+    d_mles = own.take<fe>(total);
+    d_next = own.take<fe>(half);
+    d_partials = own.take<fe>(partials.size());
+    d_products = own.take<product_desc<F>>(products.size());
+    d_terms = own.take<u32>(d.num_product_terms);
     BZ_HIP_CHECK(hipMemcpyAsync(d_raw, d.mles, static_cast<size_t>(E::element_bytes) * total,
                                 hipMemcpyHostToDevice, ds->stream));
     BZ_HIP_CHECK(hipMemcpyAsync(d_products, products.data(), sizeof(product_desc<F>) * products.size(),
@@ -259,7 +260,12 @@ void prove(api_state& st, u8* polynomials, u8* evaluation_point, const sumcheck_
     for (u32 k = 0; k < length; ++k) E::store(out + E::element_bytes * k, poly[k]);
     // the caller's transcript draws the challenge (callback_sumcheck_transcript.h:27-45)
     u8* r_bytes = evaluation_point + static_cast<size_t>(E::element_bytes) * round;
+    if (lease != nullptr) lease->unlock();
     reinterpret_cast<callback_t>(callback)(r_bytes, context, out, length);
+    if (lease != nullptr) {
+      lease->relock();
+      if (on_device) ds->activate(); // the callback may have changed the thread's current device
+    }
     if (round + 1 == num_variables) break;
     const fe r = E::load(r_bytes);
     const fe one_minus_r = fsub<F>(F::one(), r);
@@ -282,22 +288,26 @@ void prove(api_state& st, u8* polynomials, u8* evaluation_point, const sumcheck_
     }
     n = mid;
   }
-  if (on_device) BZ_HIP_CHECK(hipStreamSynchronize(ds->stream));
+  if (on_device) {
+    BZ_HIP_CHECK(hipStreamSynchronize(ds->stream));
+    own.release();
+  }
 }
 } // namespace
 
 void prove_sumcheck(api_state& st, void* polynomials, void* evaluation_point, unsigned field_id,
-                    const sumcheck_inputs& d, void* callback, void* context) {
+                    const sumcheck_inputs& d, void* callback, void* context,
+                    api_state::device_lease* lease) {
   BZ_RELEASE_ASSERT(d.n > 0, "sumcheck needs at least one row");
   BZ_RELEASE_ASSERT(d.round_degree >= 1 && d.round_degree <= kMaxDegree,
                     "round_degree must be in [1, 8]");
   BZ_RELEASE_ASSERT(d.n <= (1u << 30), "sumcheck tables are limited to 2^30 rows");
   if (field_id == 0) {
     prove<scalar25519_elements>(st, static_cast<u8*>(polynomials), static_cast<u8*>(evaluation_point),
-                                d, callback, context);
+                                d, callback, context, lease);
   } else if (field_id == 1) {
     prove<grumpkin_elements>(st, static_cast<u8*>(polynomials), static_cast<u8*>(evaluation_point), d,
-                             callback, context);
+                             callback, context, lease);
   } else {
     BZ_RELEASE_ASSERT(false, "unsupported field id");
   }

@@ -58,6 +58,10 @@ int bzamd_accumulate_form(void);
 /* number of gfx950 kernel launches issued by this process so far (tests use it to prove that the
  * HIP path, not a host path, produced a result) */
 uint64_t bzamd_kernel_launch_count(void);
+/* the most blocking sxt_* calls that ever held devices of the GPU backend at the same time (calls
+ * take per-device leases, not a process-wide lock: two host threads on a two-device backend run
+ * side by side; tests use this to prove it) */
+uint32_t bzamd_concurrent_calls_high_water(void);
 /* drop the backend singleton so that sxt_init may be called again (reference:
  * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
 void bzamd_reset_for_testing(void);

@@ -265,3 +265,61 @@ def test_stream_arrangements_of_the_throughput_mode_agree():
             assert line["outputs_agree"], (env_extra, line)
             hashes.add(line["hash"])
         assert len(hashes) == 1, hashes
+
+
+CONCURRENT_CHILD = r"""
+import json, os, sys, threading
+import numpy as np
+sys.path.insert(0, {root!r})
+backend = {backend}
+if backend == 2:
+    import torch
+from blitzar_amd import api
+from tests import util
+lib = api.load()
+assert api.init(backend, 64) == 0
+assert lib.bzamd_num_devices() == 2
+lib.bzamd_set_shard_min_bytes(1 << 40)   # every call stays on ONE of the two devices
+n = {n}
+gens = util.generators_for(0, n)
+g = util.api_generators(0, gens)
+cols = [[(np.random.default_rng(10 * t + k).integers(0, 256, (n, 32), dtype=np.uint8), False)
+         for k in range(3)] for t in range(2)]
+results = [[None] * {calls} for _ in range(2)]
+start = threading.Barrier(2)
+def worker(t):
+    start.wait()
+    for k in range({calls}):
+        results[t][k] = api.compute_pedersen_commitments(0, cols[t], generators=g).tolist()
+threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+for th in threads: th.start()
+for th in threads: th.join()
+print("RESULT" + json.dumps({{"results": results,
+                              "high_water": int(lib.bzamd_concurrent_calls_high_water())}}))
+"""
+
+
+def _concurrent_callers(oracle, backend, n, calls):
+    env = dict(os.environ, BLITZAR_AMD_FORCE_SHARDS="2")
+    env.pop("BLITZAR_BACKEND", None)
+    code = CONCURRENT_CHILD.format(root=ROOT, backend=backend, n=n, calls=calls)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith("RESULT"))[6:])
+    gens = util.generators_for(0, n)
+    for t in range(2):
+        cols = [(np.random.default_rng(10 * t + k).integers(0, 256, (n, 32), dtype=np.uint8), False)
+                for k in range(3)]
+        want = oracle.commit(0, cols, gens).tolist()
+        assert all(res == want for res in out["results"][t]), f"thread {t}: wrong commitments"
+    return out["high_water"]
+
+
+@pytest.mark.gpu
+def test_two_caller_threads_run_side_by_side_on_two_devices(oracle):
+    """blocking sxt_* calls take per-device leases (round 3: one process-wide lock): two host
+    threads on a backend of two (logical) devices are inside the library at the same time, each on
+    its own device, and both get the reference's commitments
+    (reference: thread_local per-call state, sxt/execution/schedule/scheduler.cc:65-69)"""
+    assert _concurrent_callers(oracle, 2, 1 << 16, 12) >= 2

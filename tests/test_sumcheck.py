@@ -98,3 +98,35 @@ def test_sumcheck_gpu_backend(gpu_backend, oracle, field_id, case):
 def test_sumcheck_gpu_backend_long(gpu_backend, oracle, field_id):
     """2^14 + 77 rows, degree 3: every workgroup of k_sumcheck_round contributes"""
     run_case(gpu_backend, oracle, field_id, (1 << 14) + 77, 4, [[0, 1, 2], [3, 1], [2]], 9)
+
+
+def _reentrant_case(api, oracle, field_id):
+    """the transcript callback calls back into the library while the prover is between rounds
+    (round 3 held a process-wide lock across it and would have deadlocked)"""
+    n, num_mles, products = 300, 3, [[0, 1], [2]]
+    rng = np.random.default_rng(77)
+    mles = elements(rng, field_id, n * num_mles).reshape(num_mles, n, 32)
+    lengths = [len(t) for t in products]
+    terms = [i for t in products for i in t]
+    mults = elements(rng, field_id, len(products))
+    table = product_table(field_id, mults, lengths, api.SUMCHECK_PRODUCT_STRIDE[field_id])
+    inner, seen = challenge_callback(field_id, []), []
+
+    def callback(r_ptr, ctx, poly_ptr, length):
+        seen.append(api.get_one_commit(3).copy())  # a blocking sxt_* call from inside the callback
+        inner(r_ptr, ctx, poly_ptr, length)
+
+    want = oracle.prove_sumcheck(field_id, mles, table, terms, n, max(lengths),
+                                 challenge_callback(field_id, []))
+    got = api.prove_sumcheck(field_id, mles, table, terms, n, max(lengths), callback)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert len(seen) == 9 and all(np.array_equal(s, oracle.one_commit(3)) for s in seen)
+
+
+def test_sumcheck_callback_may_reenter_host_backend(cpu_backend, oracle):
+    _reentrant_case(cpu_backend, oracle, 0)
+
+
+@pytest.mark.gpu
+def test_sumcheck_callback_may_reenter_gpu_backend(gpu_backend, oracle):
+    _reentrant_case(gpu_backend, oracle, 0)
