@@ -99,6 +99,14 @@ class Collectives:
         self.dist.all_reduce(c, op=op)
         t.copy_(c.to(t.device))
 
+    def broadcast(self, t, src):
+        if not self.host:
+            self.dist.broadcast(t, src)
+            return
+        c = t.cpu()
+        self.dist.broadcast(c, src)
+        t.copy_(c.to(t.device))
+
     def barrier(self):
         self.dist.barrier()
 
@@ -445,6 +453,65 @@ def run_configs(lib, oracle, args, dev, stream):
     torch.cuda.empty_cache()
     entries.append(config5(lib, oracle, args.config_steps, dev, stream))
     return entries
+
+
+def strong_scaling_config2(lib, args, dev, stream, rank, world, dist, coll, generators, n,
+                           rank0_commitment):
+    """N > 1: the HEADLINE column (mt19937{0}, 2^20 rows) cut into N row ranges (SURVEY 8(e) way 2):
+    rank r commits rows [r n / N, (r + 1) n / N) against the matching generator slice to a projective
+    partial (bzamd_msm_device_projective), ONE all-gather of the ranks' K x 160 bytes closes the
+    sequence and every rank folds + encodes the K commitments (bzamd_fold_encode_device).  Group
+    addition is exact, so the commitment must be rank 0's own commitment of the whole column, which
+    the reference CPU backend verified.  Strong scaling: total work fixed as N grows.
+    Reference: sxt/multiexp/curve/multiexponentiation.h:176-198 (chunks over devices, host combine)."""
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    rows = hi - lo
+    part = wl.mt19937_scalars(1, n, 32, top_mask=0x0f, seed=0)[0][lo:hi]
+    scalars = torch.from_numpy(np.ascontiguousarray(part)).to(dev)
+    gens = generators[lo:hi]
+    steps = max(args.steps, 1)
+    partials = torch.zeros((steps, 160), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world * steps, 160), dtype=torch.uint8, device=dev)
+    commitments = torch.zeros((steps, 32), dtype=torch.uint8, device=dev)
+    desc = (api.sxt_sequence_descriptor * 1)()
+    desc[0] = api.sxt_sequence_descriptor(32, rows, scalars.data_ptr(), 0)
+
+    def sequence(count):
+        for k in range(count):
+            lib.bzamd_pipeline_next()
+            lib.bzamd_msm_device_projective(0, vp(partials[k:k + 1]), 1, desc, vp(gens), stream)
+        lib.bzamd_pipeline_flush(stream)
+        coll.all_gather(gathered, partials)
+        # gathered = [rank][step][160]: exactly the partials[r * num_outputs + k] layout of the fold
+        lib.bzamd_fold_encode_device(0, vp(commitments), vp(gathered), world, steps, stream)
+
+    sequence(max(args.warmup, 2))
+    torch.cuda.synchronize()
+    coll.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sequence(steps)
+    torch.cuda.synchronize()
+    coll.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    coll.all_reduce(t, dist.ReduceOp.MAX)
+    dt = float(t.item()) / steps
+    got = commitments.cpu().numpy()
+    want = torch.from_numpy(rank0_commitment.copy()).to(dev)
+    coll.broadcast(want, 0)
+    want = want.cpu().numpy()
+    ok = bool((got == want[0]).all())
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    coll.all_reduce(flag, dist.ReduceOp.MIN)
+    assert int(flag.item()) == 1, "row-split headline column: a rank's commitment differs"
+    return {"config": f"2: curve25519 MSM, ONE column of 2^{n.bit_length() - 1} rows cut into {world} "
+                      "row ranges (projective partials, all-gather, fold + encode on every rank)",
+            "scaling": "strong", "rows_per_gpu": rows, "steps": steps, "ms_per_step": dt * 1e3,
+            "scalar_point_ops_per_s": n / dt, "commitments_per_s": 1.0 / dt,
+            "all_gather_bytes": int(gathered.numel()),
+            "verified": "every rank's K commitments equal rank 0's commitment of the whole column "
+                        "(itself bit-exact vs the reference CPU backend when the oracle is present)"}
 
 
 def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll):
@@ -794,6 +861,12 @@ def main():
                          "processes scale it by the core count)",
                "all_cores_estimate": n / cdt * (os.cpu_count() or 1)}
 
+    # N > 1: the BASELINE metric itself under strong scaling -- the headline column row-split over
+    # the ranks -- beside the (trivially linear) weak-scaling `value`
+    strong2 = None
+    if world > 1:
+        strong2 = strong_scaling_config2(lib, args, dev, stream, rank, world, dist, coll, generators,
+                                         n, timed_output)
     sharded = None
     if world > 1 and oracle is not None and not args.no_configs and 256 % world == 0:
         sharded = sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll)
@@ -868,6 +941,8 @@ def main():
             result["strong_scaling"] = {k: sharded[k] for k in
                                         ("config", "columns_per_gpu", "ms_per_call",
                                          "scalar_point_ops_per_s", "commitments_per_s", "verified")}
+        if strong2 is not None:
+            result["strong_scaling_config2"] = strong2
         if dist_info is not None:
             result["distributed"] = dist_info
 
