@@ -587,6 +587,49 @@ def in_process_multi_device():
         return {"error": repr(exc)[:300]}
 
 
+def device_state(lib, sequence_call, lone_call, stream):
+    """which box this is and what the part does under the bench's two kinds of load (tools/prof/
+    device_state.py: amd-smi / rocm-smi): idle, beside a sequence of the timed region's calls (every
+    SIMD busy: the package power limit governs the clock), and beside lone calls (40 % of a lone call
+    are single-wavefront tails).  The SMI tools take ~1 s per sample, so each load is kept up for a
+    few seconds by enqueueing ahead; untimed, after everything that is measured."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "prof"))
+    import device_state as smi
+    import threading
+    out = {"static": smi.static_info(), "idle": smi.sample()}
+    if not out["static"] and not out["idle"]:
+        return {"error": "no SMI tool answered"}
+    # ~3 s of calls in throughput mode, enqueued ahead of the device (0.1 ms of host per call)
+    calls = 3000
+    for _ in range(calls):
+        lib.bzamd_pipeline_next()
+        sequence_call()
+    time.sleep(0.6)  # past the clock ramp
+    out["under_sequence_load"] = smi.sample()
+    lib.bzamd_pipeline_flush(stream)
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    count = [0]
+
+    def lone_loop():
+        while not stop.is_set():
+            lone_call()
+            torch.cuda.synchronize()
+            count[0] += 1
+
+    t = threading.Thread(target=lone_loop)
+    t.start()
+    time.sleep(0.6)
+    out["under_lone_call_load"] = smi.sample()
+    stop.set()
+    t.join()
+    out["under_lone_call_load"]["calls_in_the_leg"] = count[0]
+    out["how"] = (f"amd-smi metric --clock --power --json (GPU 0); sequence leg: {calls} calls of the "
+                  "timed shape enqueued in throughput mode, sampled 0.6 s in; lone leg: calls with a "
+                  "device synchronisation after each, sampled 0.6 s in")
+    return out
+
+
 def host_api():
     """What a drop-in caller sees: the blocking sxt_* entry points with HOST buffers, PCIe-inclusive,
     in child processes (their own sxt_init, no torch): the native warm driver
@@ -934,6 +977,14 @@ def main():
         if cpu is not None and world == 1:
             result["cpu_baseline"] = cpu
         if world == 1 and not args.no_configs and args.log2n is None:
+            try:
+                result["device_state"] = device_state(
+                    lib, lambda: lib.bzamd_msm_device(curve_id, vp(outs[0:1]), 1, desc,
+                                                      vp(generators), stream),
+                    lambda: lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream),
+                    stream)
+            except Exception as exc:  # never at the price of the line
+                result["device_state"] = {"error": repr(exc)[:300]}
             result["configs"] = run_configs(lib, oracle, args, dev, stream)
         if sharded is not None:
             result["configs"] = [sharded]

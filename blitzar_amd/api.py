@@ -90,6 +90,8 @@ def load():
     lib.bzamd_active_backend.restype = ctypes.c_int
     lib.bzamd_kernel_launch_count.restype = ctypes.c_uint64
     lib.bzamd_concurrent_calls_high_water.restype = ctypes.c_uint32
+    lib.bzamd_set_row_pipeline_chunks.argtypes = [u32]
+    lib.bzamd_set_row_pipeline_chunks.restype = None
     lib.bzamd_reset_for_testing.restype = None
     lib.bzamd_set_tuning.argtypes = [u32, u64, u64]
     lib.bzamd_set_tuning.restype = None

@@ -327,6 +327,152 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   return d_out;
 }
 
+// rows of a blocking call in a pipeline (below): 0 = the cost model decides, k = k row chunks
+// wherever the longest column has at least k rows (tests)
+std::atomic<u32> g_row_pipeline_chunks{0};
+
+// How many row chunks a single-device call with host operands is cut into.  The upload of a call
+// runs at the link's rate whatever we do (measured on the MI355X boxes: hipMemcpyAsync from pageable
+// memory 56.5 GB/s, from pinned memory 57.5 -- profiles/round4_h2d_rates.txt), so what a call can gain
+// is overlap: chunk k computes while chunk k + 1 uploads, and only the smaller of the two sides
+// stays exposed, 1 / chunks of it.  Chunks cost work (every chunk reduces its own buckets and runs
+// its own Horner chain; short columns take narrower windows), so compute-bound shapes take few.
+u32 choose_row_chunks(const curve_vtable& vt, const std::vector<host_column>& cols, u64 longest,
+                      size_t upload_bytes) {
+  const u32 forced = g_row_pipeline_chunks.load();
+  if (forced != 0) return static_cast<u32>(std::min<u64>(forced, std::max<u64>(longest, 1)));
+  if (longest < (u64{1} << 18) || upload_bytes < (size_t{32} << 20)) return 1;
+  static const double ps_per_addition[4] = {40, 165, 66, 68}; // k_accumulate, DESIGN section 9
+  double additions = 0;
+  for (const auto& c : cols) additions += static_cast<double>(c.n) * ((c.bit_width + 15) / 16);
+  const double compute_ms = additions * ps_per_addition[vt.curve_id & 3] * 1e-9 + 0.45;
+  const double upload_ms = static_cast<double>(upload_bytes) / 55e6;
+  u32 best = 1;
+  double best_ms = upload_ms + compute_ms;
+  for (u32 r = 2; r <= 8 && (longest / r) >= (u64{1} << 16); r *= 2) {
+    const double inflated = compute_ms * (1.0 + 0.07 * (r == 2 ? 1 : (r == 4 ? 2 : 3))) + 0.12 * r;
+    const double total = std::max(upload_ms, inflated) + std::min(upload_ms, inflated) / r;
+    if (total < best_ms) {
+      best_ms = total;
+      best = r;
+    }
+  }
+  return best;
+}
+
+// The same commitment as enqueue_commitments, as a pipeline over `chunks` row ranges: the copy
+// stream uploads range k + 1 (the caller's generators of the range and every column's rows) into
+// the other of two staging regions while the engine commits range k to projective partials (in
+// throughput mode: the tails of range k run beside the front of range k + 1); one fold kernel adds
+// the partials up and encodes.  Group addition is exact: the commitments are the same bytes.
+u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curve_vtable& vt,
+                                     const std::vector<host_column>& cols, u64 longest,
+                                     const generator_ref& gens, u32 out_stride, bool projective_out,
+                                     u32 chunks, std::vector<hipEvent_t>& events) {
+  ds.activate();
+  const bool upload_generators = gens.source == generator_source::host_api;
+  const u32 num_sequences = static_cast<u32>(cols.size());
+  const u32 psize = static_cast<u32>(vt.projective_size);
+  const u64 rows_max = (longest + chunks - 1) / chunks + 1;
+  // one staging region: [caller generators | addends] + every column's rows of a range
+  size_t region_bytes = 0;
+  if (upload_generators) {
+    region_bytes += device_arena::padded(vt.api_generator_size * rows_max + 32) +
+                    device_arena::padded(vt.addend_size * (rows_max + 1));
+  }
+  for (const auto& c : cols) {
+    region_bytes += device_arena::padded(static_cast<size_t>(std::min<u64>(c.n, rows_max)) * c.row_stride + 32);
+  }
+  const size_t partial_bytes = static_cast<size_t>(psize) * num_sequences;
+  ds.io.reset(2 * region_bytes + device_arena::padded(partial_bytes * chunks) +
+                  device_arena::padded(static_cast<size_t>(out_stride) * num_sequences) + 4096,
+              ds.stream);
+  if (ds.copy_stream == nullptr) {
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&ds.copy_stream, hipStreamNonBlocking));
+  }
+  auto new_event = [&] {
+    hipEvent_t e;
+    BZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    events.push_back(e);
+    return e;
+  };
+  struct region {
+    u8* api = nullptr;
+    void* addends = nullptr;
+    std::vector<u8*> columns;
+  } regions[2];
+  for (auto& r : regions) {
+    if (upload_generators) {
+      r.api = ds.io.take<u8>(vt.api_generator_size * rows_max + 32);
+      r.addends = ds.io.take<u8>(vt.addend_size * (rows_max + 1));
+    }
+    for (const auto& c : cols) {
+      r.columns.push_back(ds.io.take<u8>(static_cast<size_t>(std::min<u64>(c.n, rows_max)) * c.row_stride + 32));
+    }
+  }
+  u8* d_partials = ds.io.take<u8>(partial_bytes * chunks);
+  u8* d_out = ds.io.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
+  // the io arena may have been reallocated on ds.stream: the copy stream starts behind it
+  hipEvent_t ready = new_event();
+  BZ_HIP_CHECK(hipEventRecord(ready, ds.stream));
+  BZ_HIP_CHECK(hipStreamWaitEvent(ds.copy_stream, ready, 0));
+  const bool resident = !upload_generators;
+  window_table tables{};
+  if (resident && ds.builtin.tables() != nullptr && longest <= ds.builtin.shape.stride - gens.offset) {
+    tables = ds.builtin.shape;
+  }
+  std::vector<hipEvent_t> computed(chunks);
+  for (u32 k = 0; k < chunks; ++k) {
+    const u64 row_begin = static_cast<u64>(static_cast<unsigned __int128>(longest) * k / chunks);
+    const u64 row_end = static_cast<u64>(static_cast<unsigned __int128>(longest) * (k + 1) / chunks);
+    region& r = regions[k & 1];
+    if (k >= 2) BZ_HIP_CHECK(hipStreamWaitEvent(ds.copy_stream, computed[k - 2], 0));
+    if (upload_generators) {
+      BZ_HIP_CHECK(hipMemcpyAsync(r.api, static_cast<const u8*>(gens.host_generators) +
+                                             vt.api_generator_size * row_begin,
+                                  vt.api_generator_size * (row_end - row_begin),
+                                  hipMemcpyHostToDevice, ds.copy_stream));
+    }
+    std::vector<host_column> mine = row_range_of(cols, row_begin, row_end);
+    for (size_t c = 0; c < mine.size(); ++c) {
+      if (mine[c].n == 0) {
+        mine[c].data = nullptr;
+        continue;
+      }
+      BZ_HIP_CHECK(hipMemcpyAsync(r.columns[c], mine[c].data,
+                                  static_cast<size_t>(mine[c].n) * mine[c].row_stride,
+                                  hipMemcpyHostToDevice, ds.copy_stream));
+      mine[c].data = r.columns[c];
+    }
+    hipEvent_t copied = new_event();
+    BZ_HIP_CHECK(hipEventRecord(copied, ds.copy_stream));
+    BZ_HIP_CHECK(hipStreamWaitEvent(ds.stream, copied, 0));
+    u8* out_k = d_partials + partial_bytes * k;
+    if (chunks > 1) msm_context_defer_next_tail(ds.ctx);
+    if (upload_generators) {
+      vt.prepare_addends(r.addends, r.api, row_end - row_begin, ds.stream);
+      g_kernel_launches += 1;
+      vt.msm(*ds.ctx, out_k, psize, true, mine, r.addends, nullptr, ds.stream);
+    } else {
+      // a range of a resident set: the same rows of every window-table slice
+      const void* d_addends = ds.builtin.rows_from(gens.offset + row_begin, vt.resident_addend_size);
+      vt.msm_resident(*ds.ctx, out_k, psize, true, mine, d_addends, ds.stream,
+                      tables.windows != 0 ? &tables : nullptr);
+    }
+    computed[k] = new_event();
+    BZ_HIP_CHECK(hipEventRecord(computed[k], ds.stream));
+  }
+  msm_context_join_tail(ds.ctx, ds.stream);
+  if (projective_out) {
+    vt.fold_device(d_out, d_partials, chunks, num_sequences, ds.stream);
+  } else {
+    vt.fold_encode_device(d_out, d_partials, chunks, num_sequences, ds.stream);
+  }
+  g_kernel_launches += 1;
+  (void)st;
+  return d_out;
+}
+
 // does a call with these columns spread over all devices of the GPU backend?
 bool shards_over_devices(const api_state& st, const checked_columns& cc) {
   size_t scalar_bytes = 0;
@@ -409,8 +555,22 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
   if (!shard && passes <= 1) {
     device_state& ds = single != nullptr ? *single : st.primary();
     std::vector<hipEvent_t> events;
-    u8* d_out = enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
-                                    projective_out, events);
+    // operands that have to travel: the scalars, and the caller's generators; built-in generators
+    // are resident when the call lies inside the init-time cache
+    const bool cached_builtin = source == generator_source::builtin &&
+                                offset_generators <= st.host_generators.size() &&
+                                cc.longest <= st.host_generators.size() - offset_generators &&
+                                ds.builtin.d_addends != nullptr;
+    u32 chunks = 1;
+    if (source == generator_source::host_api || cached_builtin) {
+      chunks = choose_row_chunks(vt, cc.cols,  cc.longest,
+                                 scalar_bytes + (cached_builtin ? 0 : vt.api_generator_size * cc.longest));
+    }
+    u8* d_out = chunks > 1
+                    ? enqueue_commitments_row_pipeline(st, ds, vt, cc.cols, cc.longest, all_gens,
+                                                       out_stride, projective_out, chunks, events)
+                    : enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
+                                          projective_out, events);
     BZ_HIP_CHECK(hipMemcpyAsync(out, d_out, static_cast<size_t>(out_stride) * num_sequences,
                                 hipMemcpyDeviceToHost, ds.stream));
     BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
@@ -1139,6 +1299,11 @@ int bzamd_num_devices(void) {
 
 void bzamd_set_shard_min_bytes(uint64_t bytes) { g_shard_min_bytes.store(bytes); }
 
+void bzamd_set_row_pipeline_chunks(uint32_t chunks) {
+  BZ_RELEASE_ASSERT(chunks <= 64, "row pipeline: at most 64 chunks (0 = automatic)");
+  g_row_pipeline_chunks.store(chunks);
+}
+
 void bzamd_set_max_rows_per_pass(uint64_t rows) {
   BZ_RELEASE_ASSERT(rows >= 1 && rows < (uint64_t{1} << 31), "rows per pass must be in [1, 2^31)");
   g_max_rows_per_pass.store(rows);
@@ -1351,7 +1516,10 @@ void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_
   // default 60): a first-ever bring-up of the fabric that never returns must not hang the caller --
   // the exchange falls back to peer copies and says so.
   if (st.exchange_state == 0) {
-    bool distinct = D > 1;
+    // (one device: tests still drive the RCCL path -- library load, communicator, collective -- with
+    // a single rank through BLITZAR_AMD_RCCL_SINGLE_DEVICE=1)
+    const char* single = std::getenv("BLITZAR_AMD_RCCL_SINGLE_DEVICE");
+    bool distinct = D > 1 || (single != nullptr && single[0] == '1');
     for (size_t a = 0; a < D; ++a) {
       for (size_t b = a + 1; b < D; ++b) distinct = distinct && st.devices[a]->device != st.devices[b]->device;
     }

@@ -41,6 +41,11 @@ int bzamd_active_backend(void);
 int bzamd_num_devices(void);
 /* calls with fewer scalar bytes than this stay on one device (default 1 MiB) */
 void bzamd_set_shard_min_bytes(uint64_t bytes);
+/* A blocking call with host operands that stays on one device is cut into row chunks when that pays:
+ * chunk k is committed to projective partials while chunk k + 1 crosses PCIe, one fold adds the
+ * partials up (exact group addition: the same commitments).  0 = the cost model decides (default);
+ * k = k chunks wherever the longest sequence has that many rows (tests). */
+void bzamd_set_row_pipeline_chunks(uint32_t chunks);
 /* rows of a sequence one pass of the engine takes (default 2^28, at most 2^31 - 1: the engine
  * indexes the rows of a pass with 31 bits).  A longer sequence -- the ABI's n is a uint64_t -- runs
  * in ceil(n / rows) passes over row ranges whose projective partial results are folded; the

@@ -705,6 +705,46 @@ def test_rows_in_several_passes(gpu_backend, oracle, curve_id):
         lib.bzamd_set_max_rows_per_pass(1 << 28)
 
 
+@pytest.mark.parametrize("curve_id", [0, 1, 3])
+@pytest.mark.parametrize("chunks", [2, 3, 7])
+def test_blocking_call_as_a_row_pipeline(gpu_backend, oracle, curve_id, chunks):
+    """a blocking call with host operands cut into row chunks (chunk k commits to projective partials
+    while chunk k + 1 uploads, one fold at the end): forced on a small input, caller and built-in
+    generators (inside and straddling the init-time cache), columns of unequal length, signed and
+    empty ones -- the same bytes as the reference"""
+    api = gpu_backend
+    lib = api.load()
+    rng = np.random.default_rng(5200 + 10 * curve_id + chunks)
+    n = 4001
+    gens = util.generators_for(curve_id, n)
+    g_api = util.api_generators(curve_id, gens)
+    cols = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False),
+            (rng.integers(0, 256, (n - 1500, 9), dtype=np.uint8), False),
+            (rng.integers(0, 256, (700, 4), dtype=np.uint8), True),
+            (np.zeros((0, 8), np.uint8), False),
+            (rng.integers(0, 256, (n, 2), dtype=np.uint8), True)]
+    want = oracle.commit(curve_id, cols, gens)
+    lib.bzamd_set_row_pipeline_chunks(chunks)
+    try:
+        before = lib.bzamd_kernel_launch_count()
+        got = api.compute_pedersen_commitments(curve_id, cols, generators=g_api)
+        assert lib.bzamd_kernel_launch_count() - before >= 6 * chunks  # every chunk ran the engine
+        assert np.array_equal(got, want)
+        if curve_id == 0:
+            # the session's backend caches 100 built-in generators: rows 0..99 resident, the rest of
+            # a longer column derived on the fly (that shape is not pipelined; it must still agree)
+            short = [(c[:90], sgn) for c, sgn in cols]
+            for off in (0, 7):
+                want_off = oracle.commit(0, short, oracle.ristretto_generators(90, off))
+                assert np.array_equal(api.compute_pedersen_commitments(0, short, offset_generators=off),
+                                      want_off)
+            want_far = oracle.commit(0, cols, oracle.ristretto_generators(n, 50))
+            assert np.array_equal(api.compute_pedersen_commitments(0, cols, offset_generators=50),
+                                  want_far)
+    finally:
+        lib.bzamd_set_row_pipeline_chunks(0)
+
+
 def test_sequence_of_2_31_plus_5_rows(gpu_backend, oracle):
     """n = 2^31 + 5 (a 2 GiB column of bytes): beyond what a 31-bit row index holds, nine passes of
     the engine against built-in generators derived on the fly.  The column is zero except for rows

@@ -191,11 +191,13 @@ def test_msm_multi_device_native_check(shards):
 
 
 @pytest.mark.gpu
-def test_msm_multi_device_matches_oracle(gpu_backend, oracle):
+def test_msm_multi_device_matches_oracle(gpu_backend, oracle, monkeypatch):
     """the multi-device entry point itself against the reference (one device here: the column
-    ranges, the padded send buffer and the RCCL exchange with a single rank)"""
+    ranges, the padded send buffer and the RCCL exchange with a single rank -- a backend of ONE
+    device skips RCCL altogether unless BLITZAR_AMD_RCCL_SINGLE_DEVICE=1 asks for it)"""
     import ctypes
     import torch
+    monkeypatch.setenv("BLITZAR_AMD_RCCL_SINGLE_DEVICE", "1")
     api = gpu_backend
     lib = api.load()
     dev = torch.device("cuda", 0)
