@@ -338,26 +338,18 @@ std::atomic<u32> g_row_pipeline_chunks{0};
 // stays exposed, 1 / chunks of it.  Chunks cost work (every chunk reduces its own buckets and runs
 // its own Horner chain; short columns take narrower windows), so compute-bound shapes take few.
 u32 choose_row_chunks(const curve_vtable& vt, const std::vector<host_column>& cols, u64 longest,
-                      size_t upload_bytes) {
+                      bool uploads_generators) {
   const u32 forced = g_row_pipeline_chunks.load();
   if (forced != 0) return static_cast<u32>(std::min<u64>(forced, std::max<u64>(longest, 1)));
-  if (longest < (u64{1} << 18) || upload_bytes < (size_t{32} << 20)) return 1;
-  static const double ps_per_addition[4] = {40, 165, 66, 68}; // k_accumulate, DESIGN section 9
-  double additions = 0;
-  for (const auto& c : cols) additions += static_cast<double>(c.n) * ((c.bit_width + 15) / 16);
-  const double compute_ms = additions * ps_per_addition[vt.curve_id & 3] * 1e-9 + 0.45;
-  const double upload_ms = static_cast<double>(upload_bytes) / 55e6;
-  u32 best = 1;
-  double best_ms = upload_ms + compute_ms;
-  for (u32 r = 2; r <= 8 && (longest / r) >= (u64{1} << 16); r *= 2) {
-    const double inflated = compute_ms * (1.0 + 0.07 * (r == 2 ? 1 : (r == 4 ? 2 : 3))) + 0.12 * r;
-    const double total = std::max(upload_ms, inflated) + std::min(upload_ms, inflated) / r;
-    if (total < best_ms) {
-      best_ms = total;
-      best = r;
-    }
-  }
-  return best;
+  // Measured on MI355X (profiles/round4_hostapi_chunks.txt, curve25519, 2^20 rows): the pipeline pays
+  // where the caller's generators dominate the upload -- one or two columns: 160 bytes of generator
+  // against 32 bytes of scalar per row and column -- and nothing of the call can start before they
+  // are all there.  Calls with many columns already overlap their column chunks with the upload
+  // (enqueue_commitments), and a call on resident generators uploads too little for chunks to
+  // recover what they cost (8 chunks: 1.78 -> 2.96 ms).
+  (void)vt;
+  if (!uploads_generators || cols.size() > 2 || longest < (u64{1} << 19)) return 1;
+  return 4;
 }
 
 // The same commitment as enqueue_commitments, as a pipeline over `chunks` row ranges: the copy
@@ -421,47 +413,95 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
   if (resident && ds.builtin.tables() != nullptr && longest <= ds.builtin.shape.stride - gens.offset) {
     tables = ds.builtin.shape;
   }
-  std::vector<hipEvent_t> computed(chunks);
+  // hipMemcpyAsync from pageable memory occupies the calling host thread for the length of the copy
+  // (the runtime stages the data itself), and enqueueing a chunk's kernels costs ~0.1 ms of host
+  // time: done by one thread, every enqueue is a gap in the upload (measured: 8 chunks 4.99 ms
+  // against 4.86 unpipelined).  So the uploads run on a helper thread, back to back; the calling
+  // thread enqueues chunk k's work as soon as the helper has issued chunk k's copies.
+  std::vector<hipEvent_t> computed(chunks), copied(chunks);
   for (u32 k = 0; k < chunks; ++k) {
-    const u64 row_begin = static_cast<u64>(static_cast<unsigned __int128>(longest) * k / chunks);
-    const u64 row_end = static_cast<u64>(static_cast<unsigned __int128>(longest) * (k + 1) / chunks);
-    region& r = regions[k & 1];
-    if (k >= 2) BZ_HIP_CHECK(hipStreamWaitEvent(ds.copy_stream, computed[k - 2], 0));
-    if (upload_generators) {
-      BZ_HIP_CHECK(hipMemcpyAsync(r.api, static_cast<const u8*>(gens.host_generators) +
-                                             vt.api_generator_size * row_begin,
-                                  vt.api_generator_size * (row_end - row_begin),
-                                  hipMemcpyHostToDevice, ds.copy_stream));
-    }
-    std::vector<host_column> mine = row_range_of(cols, row_begin, row_end);
-    for (size_t c = 0; c < mine.size(); ++c) {
-      if (mine[c].n == 0) {
-        mine[c].data = nullptr;
-        continue;
+    computed[k] = new_event();
+    copied[k] = new_event();
+  }
+  struct chunk_range {
+    u64 begin, end;
+    std::vector<host_column> columns; // device pointers once staged
+  };
+  std::vector<chunk_range> ranges(chunks);
+  for (u32 k = 0; k < chunks; ++k) {
+    ranges[k].begin = static_cast<u64>(static_cast<unsigned __int128>(longest) * k / chunks);
+    ranges[k].end = static_cast<u64>(static_cast<unsigned __int128>(longest) * (k + 1) / chunks);
+    ranges[k].columns = row_range_of(cols, ranges[k].begin, ranges[k].end);
+  }
+  std::mutex mu;
+  std::condition_variable cv;
+  u32 issued = 0;    // chunks whose copies (and `copied` event) are in the copy stream
+  u32 enqueued = 0;  // chunks whose `computed` event is in the compute stream
+  const int device = ds.device;
+  std::thread uploader([&] {
+    BZ_HIP_CHECK(hipSetDevice(device));
+    for (u32 k = 0; k < chunks; ++k) {
+      region& r = regions[k & 1];
+      if (k >= 2) {
+        // the region is free once chunk k - 2 has been computed: wait until that event has been
+        // recorded by the other thread, then let the copy stream wait for it
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return enqueued >= k - 1; });
+        lock.unlock();
+        BZ_HIP_CHECK(hipStreamWaitEvent(ds.copy_stream, computed[k - 2], 0));
       }
-      BZ_HIP_CHECK(hipMemcpyAsync(r.columns[c], mine[c].data,
-                                  static_cast<size_t>(mine[c].n) * mine[c].row_stride,
-                                  hipMemcpyHostToDevice, ds.copy_stream));
-      mine[c].data = r.columns[c];
+      const chunk_range& cr = ranges[k];
+      if (upload_generators) {
+        BZ_HIP_CHECK(hipMemcpyAsync(r.api, static_cast<const u8*>(gens.host_generators) +
+                                               vt.api_generator_size * cr.begin,
+                                    vt.api_generator_size * (cr.end - cr.begin),
+                                    hipMemcpyHostToDevice, ds.copy_stream));
+      }
+      for (size_t c = 0; c < cr.columns.size(); ++c) {
+        if (cr.columns[c].n == 0) continue;
+        BZ_HIP_CHECK(hipMemcpyAsync(r.columns[c], cr.columns[c].data,
+                                    static_cast<size_t>(cr.columns[c].n) * cr.columns[c].row_stride,
+                                    hipMemcpyHostToDevice, ds.copy_stream));
+      }
+      BZ_HIP_CHECK(hipEventRecord(copied[k], ds.copy_stream));
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        issued = k + 1;
+      }
+      cv.notify_all();
     }
-    hipEvent_t copied = new_event();
-    BZ_HIP_CHECK(hipEventRecord(copied, ds.copy_stream));
-    BZ_HIP_CHECK(hipStreamWaitEvent(ds.stream, copied, 0));
+  });
+  for (u32 k = 0; k < chunks; ++k) {
+    region& r = regions[k & 1];
+    {
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return issued > k; });
+    }
+    BZ_HIP_CHECK(hipStreamWaitEvent(ds.stream, copied[k], 0));
+    std::vector<host_column> mine = ranges[k].columns;
+    for (size_t c = 0; c < mine.size(); ++c) mine[c].data = mine[c].n == 0 ? nullptr : r.columns[c];
+    const u64 rows = ranges[k].end - ranges[k].begin;
     u8* out_k = d_partials + partial_bytes * k;
     if (chunks > 1) msm_context_defer_next_tail(ds.ctx);
     if (upload_generators) {
-      vt.prepare_addends(r.addends, r.api, row_end - row_begin, ds.stream);
+      vt.prepare_addends(r.addends, r.api, rows, ds.stream);
       g_kernel_launches += 1;
       vt.msm(*ds.ctx, out_k, psize, true, mine, r.addends, nullptr, ds.stream);
     } else {
       // a range of a resident set: the same rows of every window-table slice
-      const void* d_addends = ds.builtin.rows_from(gens.offset + row_begin, vt.resident_addend_size);
+      const void* d_addends =
+          ds.builtin.rows_from(gens.offset + ranges[k].begin, vt.resident_addend_size);
       vt.msm_resident(*ds.ctx, out_k, psize, true, mine, d_addends, ds.stream,
                       tables.windows != 0 ? &tables : nullptr);
     }
-    computed[k] = new_event();
     BZ_HIP_CHECK(hipEventRecord(computed[k], ds.stream));
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      enqueued = k + 1;
+    }
+    cv.notify_all();
   }
+  uploader.join();
   msm_context_join_tail(ds.ctx, ds.stream);
   if (projective_out) {
     vt.fold_device(d_out, d_partials, chunks, num_sequences, ds.stream);
@@ -563,8 +603,7 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
                                 ds.builtin.d_addends != nullptr;
     u32 chunks = 1;
     if (source == generator_source::host_api || cached_builtin) {
-      chunks = choose_row_chunks(vt, cc.cols,  cc.longest,
-                                 scalar_bytes + (cached_builtin ? 0 : vt.api_generator_size * cc.longest));
+      chunks = choose_row_chunks(vt, cc.cols, cc.longest, source == generator_source::host_api);
     }
     u8* d_out = chunks > 1
                     ? enqueue_commitments_row_pipeline(st, ds, vt, cc.cols, cc.longest, all_gens,

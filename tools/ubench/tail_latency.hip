@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #define CHECK(x)                                                                                   \
   do {                                                                                             \
@@ -87,6 +88,41 @@ __global__ void k_lds_roundtrip(uint64_t* out, uint32_t seed) {
   }
   out[threadIdx.x] = a;
 }
+// Instruction fetch: a dependent chain of 8-byte v_add_u32 (32-bit literal) laid out as straight-line
+// code of 16 KiB .. 256 KiB and walked `rounds` times by ONE wavefront.  The instruction cache holds
+// 64 KiB: the larger bodies are fetched from L2 / memory on every round, which is what k_reduce
+// (115-445 KB of code) and k_horner (95-257 KB) do on every call.
+#define IADD(v) asm volatile("v_add_u32 %0, 0x12345679, %0" : "+v"(v));
+#define R4(X) X X X X
+#define R16(X) R4(R4(X))
+#define R256(X) R16(R16(X))
+#define R2048(X) R4(R256(X)) R4(R256(X))
+template <int Blocks2048> __global__ void k_icache(uint64_t* out, uint32_t seed, int rounds) {
+  uint32_t a = seed + threadIdx.x;
+  for (int r = 0; r < rounds; ++r) {
+    R2048(IADD(a))
+    if constexpr (Blocks2048 >= 4) { R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) }
+    if constexpr (Blocks2048 >= 8) { R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) }
+    if constexpr (Blocks2048 >= 16) {
+      R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a))
+      R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a))
+    }
+    if constexpr (Blocks2048 >= 32) {
+      R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a))
+      R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a))
+      R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a))
+      R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a)) R2048(IADD(a))
+    }
+  }
+  out[threadIdx.x] = a;
+}
+// dependent global loads (pointer chase) of one lane over a ring of `count` 128-byte lines
+__global__ void k_chase(uint64_t* out, const uint32_t* __restrict__ ring, int steps) {
+  uint32_t at = 0;
+  for (int i = 0; i < steps; ++i) at = __builtin_nontemporal_load(&ring[static_cast<size_t>(at) * 32]);
+  out[0] = at;
+}
+
 // something to keep the rest of the chip busy
 __global__ void __launch_bounds__(256) k_heavy(uint64_t* out, uint32_t seed, int iters) {
   uint64_t a = seed + threadIdx.x, b = a * 3, c = a * 5, d = a * 7;
@@ -145,6 +181,59 @@ int main() {
       std::printf(" %14.2f", ms * 1e6 / (kIters * b.instrs_per_iter));
     }
     std::printf("\n");
+  }
+  // instruction fetch of one wavefront against the size of its code
+  std::printf("\n%-44s %12s\n", "straight-line code walked by one wavefront", "ns / instr");
+  {
+    struct { const char* name; void (*fn)(uint64_t*, uint32_t, int); int instrs; } ic[] = {
+        {"16 KiB of code (fits the 64 KiB I-cache)", k_icache<1>, 2048},
+        {"64 KiB", k_icache<4>, 4 * 2048},
+        {"128 KiB", k_icache<8>, 8 * 2048},
+        {"256 KiB", k_icache<16>, 16 * 2048},
+        {"512 KiB", k_icache<32>, 32 * 2048},
+    };
+    for (const auto& c : ic) {
+      const int rounds = (1 << 19) / c.instrs;
+      hipLaunchKernelGGL(c.fn, dim3(1), dim3(64), 0, s1, d_out, 1u, 2);
+      CHECK(hipStreamSynchronize(s1));
+      CHECK(hipEventRecord(e0, s1));
+      hipLaunchKernelGGL(c.fn, dim3(1), dim3(64), 0, s1, d_out, 2u, rounds);
+      CHECK(hipEventRecord(e1, s1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      std::printf("%-44s %12.2f\n", c.name, ms * 1e6 / (static_cast<double>(rounds) * c.instrs));
+    }
+  }
+  // dependent global loads against the footprint (L2 4 MiB per XCD, Infinity Cache 256 MiB, HBM)
+  std::printf("\n%-44s %12s\n", "pointer chase, one lane", "ns / load");
+  for (size_t mib : {1u, 32u, 1024u}) {
+    const size_t lines = (mib << 20) / 128;
+    std::vector<uint32_t> next(lines);
+    // a single cycle through all lines with a large odd stride (no hardware prefetch pattern)
+    const size_t stride = (lines / 2 + 12345) | 1;
+    for (size_t i = 0, at = 0; i < lines; ++i) {
+      const size_t to = (at + stride) % lines;
+      next[at] = static_cast<uint32_t>(to);
+      at = to;
+    }
+    uint32_t* d_ring = nullptr;
+    CHECK(hipMalloc(&d_ring, lines * 128));
+    CHECK(hipMemset(d_ring, 0, lines * 128));
+    std::vector<uint32_t> image(lines * 32, 0);
+    for (size_t i = 0; i < lines; ++i) image[i * 32] = next[i];
+    CHECK(hipMemcpy(d_ring, image.data(), lines * 128, hipMemcpyHostToDevice));
+    const int steps = 1 << 15;
+    hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, s1, d_out, d_ring, steps);
+    CHECK(hipStreamSynchronize(s1));
+    CHECK(hipEventRecord(e0, s1));
+    hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, s1, d_out, d_ring, steps);
+    CHECK(hipEventRecord(e1, s1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("%6zu MiB ring%31s %12.1f\n", mib, "", ms * 1e6 / steps);
+    CHECK(hipFree(d_ring));
   }
   return 0;
 }
