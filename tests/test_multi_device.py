@@ -251,11 +251,19 @@ def test_stream_arrangements_of_the_throughput_mode_agree():
         ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_PRIORITY": "0",
           "BLITZAR_AMD_DEDICATED_QUEUES": "0"}, []),
         ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_CUS": "64"}, []),
+        # the round-3 forms of the sort's front (round 4 fused them; kept as A/B knobs)
+        ({"BLITZAR_AMD_FUSE_OFFSETS": "0"}, []),
+        ({"BLITZAR_AMD_FUSE_BIG": "1"}, []),
+        ({"BLITZAR_AMD_FUSE_BIG": "0", "BLITZAR_AMD_RANK_ONCE": "0"}, []),
     ]
     # (2^19 rows x 16 windows: long enough for the throughput mode's own reduce geometry, plan.h)
-    for curve, log2n, columns in ((0, 15, 1), (2, 13, 3), (0, 19, 1)):
+    # (--skew: two rows in three hold one scalar -- oversized bucket groups, the chunked sort path
+    # with its in-launch barrier, the heavy-bucket folding of k_reduce)
+    for curve, log2n, columns, shape in ((0, 15, 1, []), (2, 13, 3, []), (0, 19, 1, []),
+                                         (0, 19, 1, ["--skew"]), (2, 17, 2, ["--skew"])):
         hashes = set()
-        for env_extra, flags in arrangements:
+        for env_extra, more in arrangements:
+            flags = more + shape
             env = {k: v for k, v in os.environ.items() if not k.startswith("BLITZAR_AMD_")}
             env["BLITZAR_AMD_NUM_DEVICES"] = "1"
             env.update(env_extra)

@@ -2,7 +2,8 @@
 // runs on the GPU box: no Python, no torch import -- a variant costs a second or two of box time.
 //
 //   pipeline_bench [--curve 0..3] [--log2n 20] [--columns 1] [--steps 200] [--warmup 10]
-//                  [--nbytes 32] [--null-stream] [--resident] [--lone]
+//                  [--nbytes 32] [--null-stream] [--resident] [--skew]
+//   --skew: two rows in three hold the same scalar (oversized bucket groups: the chunked sort path)
 //
 // One step = one bzamd_msm_device call of `columns` columns of 2^log2n uniform scalars (xorshift
 // bytes; 32-byte columns masked to 252 bits) against caller generators: curve25519 the built-in
@@ -42,7 +43,7 @@ static double now_ms() {
 
 int main(int argc, char** argv) {
   unsigned curve = 0, log2n = 20, columns = 1, steps = 200, warmup = 10, nbytes = 32;
-  bool null_stream = false, resident = false;
+  bool null_stream = false, resident = false, skew = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&] { return static_cast<unsigned>(std::atoi(argv[++i])); };
@@ -54,6 +55,7 @@ int main(int argc, char** argv) {
     else if (a == "--nbytes") nbytes = next();
     else if (a == "--null-stream") null_stream = true;
     else if (a == "--resident") resident = true;
+    else if (a == "--skew") skew = true;
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());
       return 2;
@@ -76,6 +78,11 @@ int main(int argc, char** argv) {
   }
   if (nbytes == 32) {
     for (size_t r = 0; r < static_cast<size_t>(columns) * n; ++r) host[r * 32 + 31] &= 0x0f;
+  }
+  if (skew) {
+    for (size_t r = 0; r < static_cast<size_t>(columns) * n; ++r) {
+      if (r % 3 != 0) std::memcpy(&host[r * nbytes], &host[0], nbytes);
+    }
   }
   uint8_t* d_scalars = nullptr;
   CHECK(hipMalloc(&d_scalars, host.size()));
