@@ -64,6 +64,11 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_FAST_RECODE", ctx->fast_recode);
   flag("BLITZAR_AMD_TAIL_LOW_PRIORITY", ctx->tail_low_priority);
   flag("BLITZAR_AMD_FUSE_OFFSETS", ctx->fuse_offsets);
+  if (const char* v = std::getenv("BLITZAR_AMD_SORT_STREAM_FACTOR")) {
+    const unsigned long f = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(f >= 1 && f <= 16, "BLITZAR_AMD_SORT_STREAM_FACTOR must be in [1, 16]");
+    ctx->sort_stream_factor = static_cast<u32>(f);
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_FUSE_BIG")) {
     const unsigned long m = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(m <= 2, "BLITZAR_AMD_FUSE_BIG must be 0, 1 or 2");

@@ -202,6 +202,10 @@ struct msm_context {
   // of its own, 1: its histogram phase, 2: both phases (a barrier among its workers in between)
   u32 fuse_big = 2;
   bool rank_once = true;    // BLITZAR_AMD_RANK_ONCE: one LDS atomic per record in scatter and sort
+  // a bucket group of up to this many times kLocalSortCapacity records is streamed by ONE workgroup
+  // of pass 2; larger ones are cut into chunks shared by the workers of the chunked path
+  // (BLITZAR_AMD_SORT_STREAM_FACTOR, 1..16)
+  u32 sort_stream_factor = 16;
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
     hipStream_t s = nullptr;
     if (mask != nullptr || dedicated_queues) {
@@ -738,16 +742,17 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   u32 sort_launches = 0;
   ctx.timer.timed(timing, 2, fs, [&] {
     u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
+    const u32 stream_limit = ctx.sort_stream_factor * kLocalSortCapacity;
     // pass 1a (+ 1b in the last workgroup of every task)
     hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
                        part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks,
                        ctx.fuse_offsets ? b.arrivals : static_cast<u32*>(nullptr), b.group_start,
-                       b.group_chunk, b.bucket_count, bucket_fill);
+                       b.group_chunk, b.bucket_count, bucket_fill, stream_limit);
     sort_launches += 1;
     if (!ctx.fuse_offsets) {
       hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, fs, b.group_cursor,
                          b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
-                         b.tasks);
+                         b.tasks, stream_limit);
       sort_launches += 1;
     }
     // all tasks of a launch share one variant: staged unless some column needs the direct form

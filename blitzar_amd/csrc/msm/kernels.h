@@ -415,9 +415,12 @@ __device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig
 }
 
 // chunks an oversized group of `total` records is cut into in pass 2 (0: one workgroup sorts it)
+// `stream_limit` = records up to which ONE workgroup streams a group through LDS in rounds of
+// kLocalSortCapacity (msm_context::sort_stream_factor x the capacity); beyond it the group goes to
+// the chunked path, whose workers share its chunks
 constexpr u32 kStreamedSortRecords = 16 * kLocalSortCapacity;
-__device__ __forceinline__ u32 big_chunks_of(u32 total) {
-  return total <= kStreamedSortRecords ? 0 : (total + kLocalSortCapacity - 1) / kLocalSortCapacity;
+__device__ __forceinline__ u32 big_chunks_of(u32 total, u32 stream_limit) {
+  return total <= stream_limit ? 0 : (total + kLocalSortCapacity - 1) / kLocalSortCapacity;
 }
 
 // Pass 1b, one workgroup of T threads per task: exclusive scans over the groups.
@@ -433,7 +436,8 @@ __device__ __forceinline__ void
 group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ group_cursor,
                     u32* __restrict__ group_start, u32* __restrict__ group_chunk,
                     u32* __restrict__ bucket_count, u32* __restrict__ bucket_fill,
-                    u32* __restrict__ big_tasks, u32* wave_sums, u32* wave_chunks) {
+                    u32* __restrict__ big_tasks, u32* wave_sums, u32* wave_chunks,
+                    u32 stream_limit) {
   constexpr u32 kWaves = T / 64;
   const u32 groups = task.num_groups;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -445,7 +449,7 @@ group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ gro
     const u32 g = g0 + tid;
     const u32 total =
         g < groups ? __hip_atomic_load(&cur[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    const u32 chunks = g < groups ? big_chunks_of(total) : 0;
+    const u32 chunks = g < groups ? big_chunks_of(total, stream_limit) : 0;
     u32 incl = total, chunk_incl = chunks;
 #pragma unroll
     for (u32 off = 1; off < 64; off <<= 1) {
@@ -506,7 +510,7 @@ static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two wo
                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks,
                  u32* __restrict__ arrivals, u32* __restrict__ group_start,
                  u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
-                 u32* __restrict__ bucket_fill) {
+                 u32* __restrict__ bucket_fill, u32 stream_limit) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   __shared__ u32 wave_sums[kSortThreads / 64];
   __shared__ u32 wave_chunks[kSortThreads / 64];
@@ -546,19 +550,20 @@ static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two wo
   __syncthreads();
   if (last_flag == 0) return;
   group_offsets_block<kSortThreads>(task, blockIdx.y, group_total, group_start, group_chunk,
-                                    bucket_count, bucket_fill, big_tasks, wave_sums, wave_chunks);
+                                    bucket_count, bucket_fill, big_tasks, wave_sums, wave_chunks,
+                                    stream_limit);
 }
 
 static __global__ void __launch_bounds__(256)
     k_group_offsets(u32* __restrict__ group_cursor, u32* __restrict__ group_start,
                     u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
                     u32* __restrict__ bucket_fill, u32* __restrict__ big_tasks,
-                    const task_desc* __restrict__ tasks) {
+                    const task_desc* __restrict__ tasks, u32 stream_limit) {
   __shared__ u32 wave_sums[4];
   __shared__ u32 wave_chunks[4];
   const task_desc task = tasks[blockIdx.x];
   group_offsets_block<256>(task, blockIdx.x, group_cursor, group_start, group_chunk, bucket_count,
-                           bucket_fill, big_tasks, wave_sums, wave_chunks);
+                           bucket_fill, big_tasks, wave_sums, wave_chunks, stream_limit);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
