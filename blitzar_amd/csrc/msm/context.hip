@@ -75,6 +75,7 @@ msm_context* msm_context_new() {
     ctx->fuse_big = static_cast<u32>(m);
   }
   flag("BLITZAR_AMD_RANK_ONCE", ctx->rank_once);
+  flag("BLITZAR_AMD_COMPACT_TAILS", ctx->compact_reduce);
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");

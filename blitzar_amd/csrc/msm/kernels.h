@@ -1590,6 +1590,258 @@ __global__ void __launch_bounds__(kReduceThreads)
   }
 }
 
+// k_reduce with few copies of the point addition (round 4).  The form above inlines C::add at ten
+// places (115 KB of code for curve25519, 226-445 KB for the Weierstrass curves), a wavefront walks
+// nearly all of it once, and the instruction cache holds 64 KB.  On one of the two kinds of MI355X
+// boxes in the pool that is harmless -- a wavefront fetches straight-line code as fast as it executes
+// it -- on the other kind code beyond the cache arrives at half the speed (6.3 against 3.5 ns per
+// instruction, tools/ubench/tail_latency.hip, profiles/round4_tail_latency_*), and this kernel takes
+// 0.32 instead of 0.18 ms.  Here the same arithmetic runs through TWO addition sites that loops
+// return to: one for the bucket walk (head partials, s += B, r += s take turns in it) and one for
+// everything that exchanges points through LDS (suffix scan or lane weights, the tree, the folding
+// of heavy buckets).  The operands are moved into place around each site (~100 register moves per
+// 1250-instruction addition); the code a wavefront executes fits the cache.
+template <class C>
+__global__ void __launch_bounds__(kReduceThreads)
+    k_reduce_compact(typename C::point* __restrict__ partials, u32 partial_stride,
+                     u32* __restrict__ task_total, const typename C::point* __restrict__ bucket_sums,
+                     const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
+                     const task_desc* __restrict__ tasks, u32 lane_log2) {
+  using point = typename C::point;
+  __shared__ point tree[kReduceThreads];
+  __builtin_amdgcn_s_setprio(BZ_REDUCE_PRIO);
+  const task_desc task = tasks[blockIdx.y];
+  const u32 nb = task.num_buckets;
+  const u32 seg_log2 = task.segment_log2;
+  const u32 lane_buckets = 1u << lane_log2;
+  const u32 block_first = blockIdx.x * (kReduceThreads << lane_log2);
+  if (block_first >= nb) return;
+  const u32 tid = threadIdx.x;
+  const u32* ends = bucket_end + task.bucket_base;
+  const u32 total = ends[nb - 1];
+  if (blockIdx.x == 0 && tid == 0) task_total[blockIdx.y] = total;
+  point* dst = partials + static_cast<u64>(blockIdx.y) * partial_stride + blockIdx.x;
+  const u32 block_end = block_first + (kReduceThreads << lane_log2) < nb
+                            ? block_first + (kReduceThreads << lane_log2)
+                            : nb;
+  if (total == 0 || ends[block_end - 1] == (block_first == 0 ? 0 : ends[block_first - 1])) {
+    if (tid == 0) *dst = C::identity();
+    return;
+  }
+  const u32 seg_first = block_first + tid * lane_buckets;
+  const point* bs = bucket_sums + task.bucket_base;
+  const point* hd = heads + task.segment_base;
+  __shared__ u32 heavy_bucket[kReduceMaxHeavy];
+  __shared__ u32 heavy_count;
+  __shared__ point heavy_sum[kReduceMaxHeavy];
+  if (tid == 0) heavy_count = 0;
+  __syncthreads();
+  const u32 seg_last = seg_first < nb ? (seg_first + lane_buckets < nb ? seg_first + lane_buckets : nb)
+                                      : seg_first;
+  if (seg_first < nb) {
+    u32 begin = seg_first == 0 ? 0 : ends[seg_first - 1];
+    for (u32 b = seg_first; b < seg_last; ++b) {
+      const u32 end = ends[b];
+      if (end != begin && heads_of(begin, end, seg_log2).count > kReduceHeavyHeads) {
+        const u32 slot = atomicAdd(&heavy_count, 1u);
+        if (slot < kReduceMaxHeavy) heavy_bucket[slot] = b;
+      }
+      begin = end;
+    }
+  }
+  __syncthreads();
+  const u32 num_heavy = heavy_count < kReduceMaxHeavy ? heavy_count : kReduceMaxHeavy;
+
+  point s = C::identity();
+  point r = C::identity();
+  bool populated = false;
+
+  // ---- heavy buckets: one addition site, three kinds of step ----------------------------------------
+  // every step: each lane publishes a point in its LDS slot, the active lanes add the point of slot
+  // `src` to their partial.  Gather steps publish a head partial for the lane itself, tree steps the
+  // partial for a lane `stride` below, the last step the bucket's own partial for lane 0.
+  for (u32 h = 0; h < num_heavy; ++h) {
+    const u32 b = heavy_bucket[h];
+    const bucket_heads list = heads_of(b == 0 ? 0 : ends[b - 1], ends[b], seg_log2);
+    point part = C::identity();
+    const u32 gathers = (list.count + kReduceThreads - 1) / kReduceThreads;
+    for (u32 step = 0; step < gathers + 9; ++step) {
+      bool act;
+      u32 src = tid;
+      point publish = part;
+      if (step < gathers) {
+        const u32 j = tid + step * kReduceThreads;
+        act = j < list.count;
+        if (act) publish = hd[list.index(j)];
+      } else if (step < gathers + 8) {
+        const u32 stride = (kReduceThreads / 2) >> (step - gathers);
+        act = tid < stride && tid + stride < list.count;
+        if (act) src = tid + stride;
+      } else {
+        act = tid == 0;
+        if (act) publish = bs[b];
+      }
+      tree[tid] = publish;
+      __syncthreads();
+      const point other = tree[src];
+      const point out = C::add(part, other);
+      if (act) part = out;
+      __syncthreads();
+    }
+    if (tid == 0) heavy_sum[h] = part;
+    __syncthreads();
+  }
+
+  // ---- the bucket walk: one addition site, three roles -------------------------------------------
+  {
+    const u32 lo = seg_first < nb ? (seg_first == 0 ? 0 : ends[seg_first - 1]) : 0;
+    const u32 hi = seg_first < nb ? ends[seg_last - 1] : 0;
+    populated = seg_first < nb && hi != lo;
+    u32 end = hi;
+    for (u32 k = lane_buckets; k-- > 0;) {
+      const u32 b = seg_first + k;
+      const bool valid = populated && b < seg_last;
+      if (__ballot(valid) == 0) continue; // nothing for this wavefront at this offset
+      const u32 begin = valid ? (b == 0 ? 0 : ends[b - 1]) : 0;
+      const bool nonempty = valid && begin != end;
+      point v = C::identity();
+      u32 hs = 1, hlast = 0, after_whole = 0; // the head partials load_bucket would visit
+      if (nonempty) {
+        u32 folded = kReduceMaxHeavy;
+        if (num_heavy != 0 && heads_of(begin, end, seg_log2).count > kReduceHeavyHeads) {
+          for (u32 h = 0; h < num_heavy; ++h) folded = heavy_bucket[h] == b ? h : folded;
+        }
+        if (folded < kReduceMaxHeavy) {
+          v = heavy_sum[folded];
+        } else {
+          v = bs[b];
+          hs = (begin >> seg_log2) + 1;
+          hlast = (end - 1) >> seg_log2;
+          after_whole = end >> seg_log2;
+        }
+      }
+      u32 phase = 0; // 0: v += head partial, 1: s += v, 2: r += s   (uniform over the wavefront)
+      for (;;) {
+        bool act;
+        point pa, pb;
+        if (phase == 0) {
+          act = nonempty && hs <= hlast;
+          if (__ballot(act) == 0) {
+            phase = 1;
+            continue;
+          }
+          pa = v;
+          pb = act ? hd[hs] : v;
+        } else if (phase == 1) {
+          act = nonempty;
+          pa = s;
+          pb = v;
+        } else {
+          act = valid;
+          pa = r;
+          pb = s;
+        }
+        const point out = C::add(pa, pb);
+        if (phase == 0) {
+          if (act) {
+            v = out;
+            if (hs < after_whole) {
+              const u32 next_wave = (hs / 64 + 1) * 64;
+              hs = next_wave < after_whole ? next_wave : after_whole;
+            } else {
+              ++hs;
+            }
+          }
+        } else if (phase == 1) {
+          if (act) s = out;
+          phase = 2;
+        } else {
+          if (act) r = out;
+          break;
+        }
+      }
+      if (valid) end = begin;
+    }
+  }
+
+  // ---- lane weights and the tree: one addition site --------------------------------------------------
+  // every step as above: publish a point, add the point of slot `src` where active
+  if constexpr (C::has_wave_add_multiple) {
+    // steps 0..7: inclusive suffix scan of s over the lanes; step 8: v_t = r_t + 2^lane_log2 suffix_t
+    // (t >= 1; the multiple is published for the lane itself); steps 9..16: the tree over v_t
+    point val = s;
+    point x = s;
+    for (u32 step = 0; step < 17; ++step) {
+      u32 src = tid;
+      bool act;
+      point publish = val;
+      if (step < 8) {
+        act = tid + (1u << step) < kReduceThreads;
+        if (act) src = tid + (1u << step);
+      } else if (step == 8) {
+        x = val; // this lane's inclusive suffix sum (lane 0: the sum of the block's buckets)
+        publish = C::dbl_n(val, static_cast<int>(lane_log2));
+        val = r;
+        act = tid != 0;
+      } else {
+        const u32 stride = (kReduceThreads / 2) >> (step - 9);
+        act = tid < stride;
+        if (act) src = tid + stride;
+      }
+      tree[tid] = publish;
+      __syncthreads();
+      const point other = tree[src];
+      const point out = C::add(val, other);
+      if (act) val = out;
+      __syncthreads();
+    }
+    if (block_first == 0) {
+      if (tid == 0) *dst = val;
+      return;
+    }
+    if (tid == 0) {
+      tree[0] = val;
+      tree[1] = x;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const point sum = C::wave_add_multiple(tree[0], tree[1], block_first);
+      if (tid == 0) *dst = sum;
+    }
+  } else {
+    // contrib_t = r_t + seg_first * s_t: seg_first by double-and-add from the top bit of the block's
+    // last bucket index down (complete formulas: doubling or adding the identity is harmless), then
+    // the tree.  Steps: `bits` x (m = 2 m; m += s where the bit is set) | contrib = r + m | 8 tree steps
+    const u32 bits = block_end > 1 ? 32 - __builtin_clz(block_end - 1) : 0;
+    point val = C::identity(); // m, then contrib
+    for (u32 step = 0; step < bits + 1 + 8; ++step) {
+      u32 src = tid;
+      bool act;
+      point publish = val;
+      if (step < bits) {
+        val = C::dbl_n(val, 1);
+        publish = s;
+        act = populated && ((seg_first >> (bits - 1 - step)) & 1u) != 0;
+      } else if (step == bits) {
+        // publish m, continue with r
+        val = r;
+        act = populated && seg_first != 0;
+      } else {
+        const u32 stride = (kReduceThreads / 2) >> (step - bits - 1);
+        act = tid < stride;
+        if (act) src = tid + stride;
+      }
+      tree[tid] = publish;
+      __syncthreads();
+      const point other = tree[src];
+      const point out = C::add(val, other);
+      if (act) val = out;
+      __syncthreads();
+    }
+    if (tid == 0) *dst = val;
+  }
+}
+
 //--------------------------------------------------------------------------------------------------
 // k_horner
 //--------------------------------------------------------------------------------------------------
@@ -1601,7 +1853,9 @@ __global__ void __launch_bounds__(kReduceThreads)
 // continues from state[column].  `last`: the range ends at window 0: write the canonical encoding
 // (or the raw projective point when `projective_out`); otherwise leave the chain value in
 // state[column].  The whole column in one launch = first && last with the full range.
-template <class C>
+// Compact (round 4, see k_reduce_compact): the window sums through ONE addition site -- the gather
+// of a team's partials and its tree take turns in one loop -- instead of two.
+template <class C, bool Compact = false>
 __global__ void __launch_bounds__(kCombineThreads)
     k_horner(u8* __restrict__ out, u32 out_stride, int projective_out,
              typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
@@ -1649,16 +1903,47 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 reduce_block = kReduceThreads << reduce_seg_log2; // buckets per k_reduce block
   const u32 blocks = (nb + reduce_block - 1) / reduce_block;
   point sum = C::identity();
-  if (w < W && lane < blocks) {
-    const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;
-    sum = p[lane];
-    for (u32 blk = lane + team; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
-  }
-  tree[tid] = sum;
-  __syncthreads();
-  for (u32 stride = team / 2; stride > 0; stride >>= 1) {
-    if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
+  if constexpr (Compact) {
+    // steps: ceil(blocks / team) gathers (a lane publishes its next partial for itself), then the
+    // tree over the team (a lane publishes its sum for the lane `stride` below)
+    const point* p = partials + static_cast<u64>(col.first_task + w_lo + (w < W ? w : 0)) * partial_stride;
+    const u32 gathers = (blocks + team - 1) / team;
+    u32 tree_steps = 0;
+    while ((1u << tree_steps) < team) ++tree_steps;
+    for (u32 step = 0; step < gathers + tree_steps; ++step) {
+      bool act;
+      u32 src = tid;
+      point publish = sum;
+      if (step < gathers) {
+        const u32 blk = lane + step * team;
+        act = w < W && blk < blocks;
+        if (act) publish = p[blk];
+      } else {
+        const u32 stride = (team / 2) >> (step - gathers);
+        act = w < W && lane < stride;
+        if (act) src = tid + stride;
+      }
+      tree[tid] = publish;
+      __syncthreads();
+      const point other = tree[src];
+      const point sum_out = C::add(sum, other);
+      if (act) sum = sum_out;
+      __syncthreads();
+    }
+    tree[tid] = sum;
     __syncthreads();
+  } else {
+    if (w < W && lane < blocks) {
+      const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;
+      sum = p[lane];
+      for (u32 blk = lane + team; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
+    }
+    tree[tid] = sum;
+    __syncthreads();
+    for (u32 stride = team / 2; stride > 0; stride >>= 1) {
+      if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
+      __syncthreads();
+    }
   }
   // all lanes of the first wavefront run the chain: keeping the data in vector registers stops
   // hipcc from moving the multi-limb chain onto the scalar unit (it did: s_mul_hi_u32 chains with
