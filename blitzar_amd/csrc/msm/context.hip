@@ -75,7 +75,11 @@ msm_context* msm_context_new() {
     ctx->fuse_big = static_cast<u32>(m);
   }
   flag("BLITZAR_AMD_RANK_ONCE", ctx->rank_once);
-  flag("BLITZAR_AMD_COMPACT_TAILS", ctx->compact_reduce);
+  if (const char* v = std::getenv("BLITZAR_AMD_COMPACT_TAILS")) {
+    const unsigned long m = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(m <= 3, "BLITZAR_AMD_COMPACT_TAILS must be 0 (off), 1 (both), 2 (horner), 3 (reduce)");
+    ctx->compact_tails = static_cast<u32>(m);
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");

@@ -209,7 +209,7 @@ struct msm_context {
   // BLITZAR_AMD_COMPACT_TAILS: k_reduce_compact and k_horner<C, true> (the point addition at three
   // places instead of ten / one instead of two: the code a wavefront walks fits the instruction
   // cache) instead of the fully inlined forms
-  bool compact_reduce = false;
+  u32 compact_tails = 0; // 0: neither, 1: both, 2: k_horner only, 3: k_reduce only
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
     hipStream_t s = nullptr;
     if (mask != nullptr || dedicated_queues) {
@@ -834,7 +834,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   if (mode.piped) ctx.acc_done[k & 3].wait(rs);
   wait_for(earlier(ctx.horner_done, 2), rs);
   ctx.timer.timed(timing, 4, rs, [&] {
-    if (ctx.compact_reduce) {
+    if (ctx.compact_tails == 1 || ctx.compact_tails == 3) {
       hipLaunchKernelGGL((k_reduce_compact<C>), dim3(b.partial_stride, num_tasks),
                          dim3(kReduceThreads), 0, rs, b.partials, b.partial_stride, b.task_total,
                          b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
@@ -849,7 +849,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // ---- horner: whole columns in one launch (the range covers every window, first and last)
   if (mode.piped) ctx.reduce_done[k & 3].wait(hs);
   ctx.timer.timed(timing, 5, hs, [&] {
-    if (ctx.compact_reduce) {
+    if (ctx.compact_tails == 1 || ctx.compact_tails == 2) {
       hipLaunchKernelGGL((k_horner<C, true>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                          out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
                          b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,

@@ -1683,25 +1683,31 @@ __global__ void __launch_bounds__(kReduceThreads)
       }
       tree[tid] = publish;
       __syncthreads();
-      const point other = tree[src];
-      const point out = C::add(part, other);
-      if (act) part = out;
+      if (__ballot(act) != 0) { // (a wavefront with no active lane skips the addition, not the barriers)
+        const point other = tree[src];
+        const point out = C::add(part, other);
+        if (act) part = out;
+      }
       __syncthreads();
     }
     if (tid == 0) heavy_sum[h] = part;
     __syncthreads();
   }
 
-  // ---- the bucket walk: one addition site, three roles -------------------------------------------
+  // ---- the bucket walk: one addition site, three roles ---------------------------------------------
+  // per bucket (from the lane's last one down): v = the bucket's partials, s += v, r += s.  The
+  // r += s of a bucket runs at the top of the NEXT iteration, while the loads of that iteration's
+  // bucket are in flight (one extra iteration at the end finishes the last bucket).
   {
     const u32 lo = seg_first < nb ? (seg_first == 0 ? 0 : ends[seg_first - 1]) : 0;
     const u32 hi = seg_first < nb ? ends[seg_last - 1] : 0;
     populated = seg_first < nb && hi != lo;
     u32 end = hi;
-    for (u32 k = lane_buckets; k-- > 0;) {
-      const u32 b = seg_first + k;
-      const bool valid = populated && b < seg_last;
-      if (__ballot(valid) == 0) continue; // nothing for this wavefront at this offset
+    bool prev_valid = false;
+    for (u32 it = 0; it <= lane_buckets; ++it) {
+      const u32 b = seg_first + (lane_buckets - 1 - it); // (wraps in the extra iteration: unused)
+      const bool valid = it != lane_buckets && populated && b < seg_last;
+      if (__ballot(valid || prev_valid) == 0) continue; // nothing for this wavefront here
       const u32 begin = valid ? (b == 0 ? 0 : ends[b - 1]) : 0;
       const bool nonempty = valid && begin != end;
       point v = C::identity();
@@ -1720,11 +1726,17 @@ __global__ void __launch_bounds__(kReduceThreads)
           after_whole = end >> seg_log2;
         }
       }
-      u32 phase = 0; // 0: v += head partial, 1: s += v, 2: r += s   (uniform over the wavefront)
+      // phases, uniform over the wavefront: 2 (r += s of the previous bucket), then 0 (v += a head
+      // partial, as long as some lane has one), then 1 (s += v)
+      u32 phase = 2;
       for (;;) {
         bool act;
         point pa, pb;
-        if (phase == 0) {
+        if (phase == 2) {
+          act = prev_valid;
+          pa = r;
+          pb = s;
+        } else if (phase == 0) {
           act = nonempty && hs <= hlast;
           if (__ballot(act) == 0) {
             phase = 1;
@@ -1732,34 +1744,36 @@ __global__ void __launch_bounds__(kReduceThreads)
           }
           pa = v;
           pb = act ? hd[hs] : v;
-        } else if (phase == 1) {
+        } else {
           act = nonempty;
           pa = s;
           pb = v;
-        } else {
-          act = valid;
-          pa = r;
-          pb = s;
         }
-        const point out = C::add(pa, pb);
-        if (phase == 0) {
+        if (__ballot(act) != 0) {
+          const point out = C::add(pa, pb);
           if (act) {
-            v = out;
-            if (hs < after_whole) {
-              const u32 next_wave = (hs / 64 + 1) * 64;
-              hs = next_wave < after_whole ? next_wave : after_whole;
+            if (phase == 2) {
+              r = out;
+            } else if (phase == 0) {
+              v = out;
+              if (hs < after_whole) {
+                const u32 next_wave = (hs / 64 + 1) * 64;
+                hs = next_wave < after_whole ? next_wave : after_whole;
+              } else {
+                ++hs;
+              }
             } else {
-              ++hs;
+              s = out;
             }
           }
+        }
+        if (phase == 2) {
+          phase = 0;
         } else if (phase == 1) {
-          if (act) s = out;
-          phase = 2;
-        } else {
-          if (act) r = out;
           break;
         }
       }
+      prev_valid = valid;
       if (valid) end = begin;
     }
   }
@@ -1790,9 +1804,11 @@ __global__ void __launch_bounds__(kReduceThreads)
       }
       tree[tid] = publish;
       __syncthreads();
-      const point other = tree[src];
-      const point out = C::add(val, other);
-      if (act) val = out;
+      if (__ballot(act) != 0) {
+        const point other = tree[src];
+        const point out = C::add(val, other);
+        if (act) val = out;
+      }
       __syncthreads();
     }
     if (block_first == 0) {
@@ -1833,9 +1849,11 @@ __global__ void __launch_bounds__(kReduceThreads)
       }
       tree[tid] = publish;
       __syncthreads();
-      const point other = tree[src];
-      const point out = C::add(val, other);
-      if (act) val = out;
+      if (__ballot(act) != 0) {
+        const point other = tree[src];
+        const point out = C::add(val, other);
+        if (act) val = out;
+      }
       __syncthreads();
     }
     if (tid == 0) *dst = val;

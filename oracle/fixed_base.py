@@ -1,11 +1,14 @@
 """TEST INFRASTRUCTURE ONLY: CPU restatement of the reference's fixed-base MSM ("pippenger2").
 
-The reference's fixed-base path cannot be compiled in this container: partition_product.h,
-reduce.h, combine_reduce.h and multiexponentiation.h include sxt/algorithm/iteration/for_each.h
-(`__global__`, `<<<>>>`) and the accessor pulls <format> + cuda_runtime.h + spdlog.
-What *does* compile -- the partition-table builder (sxt/multiexp/pippenger2/partition_table.h:
-36-98) and every curve operation -- is used from oracle/_ref; the remaining ~60 lines of control
-flow are restated here, each function citing the reference lines it follows:
+Round 1 could not compile the reference's fixed-base path (partition_product.h, reduce.h,
+combine_reduce.h and multiexponentiation.h include sxt/algorithm/iteration/for_each.h -- `__global__`,
+`<<<>>>` -- and the accessor pulls the CUDA runtime) and restated its ~60 lines of control flow here
+over the parts that did compile: the partition-table builder (sxt/multiexp/pippenger2/
+partition_table.h:36-98) and every curve operation, from oracle/_ref.  Since round 4 the reference's
+OWN path is compiled in place as well (oracle/ref/ref_fixed_base.cc over host stand-ins for the CUDA
+runtime; ref_oracle.FixedHandle: host loop and GPU control flow), and this restatement is kept as a
+second opinion that tests/test_oracle.py pins against it.  Each function cites the reference lines it
+follows:
 
   pad_generators        in_memory_partition_table_accessor_utility.h:41-58
   partition_index       partition_product.h:47-67   (compute_partition_index)
@@ -17,9 +20,10 @@ flow are restated here, each function citing the reference lines it follows:
                         :101-109; the host loop's product_index mutation at :145-148 is a latent
                         bug that only matters for zero-length outputs)
 
-Pinning: tests/test_fixed_base_cpu.py checks this restatement against the reference's own
-variable-base CPU backend (oracle/_ref) on the same scalars unpacked to columns, and against the
-known answers of cbindings/fixed_pedersen.t.cc:51-200 expressed as group expressions.
+Pinning: tests/test_oracle.py checks this restatement against the reference's own compiled
+fixed-base path (host loop and GPU control flow), against its variable-base CPU backend (oracle/_ref)
+on the same scalars unpacked to columns, and against the known answers of
+cbindings/fixed_pedersen.t.cc:51-200 expressed as group expressions.
 
 Only tests/ may import this module; the product never does.
 """
