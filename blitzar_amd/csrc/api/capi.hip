@@ -1366,6 +1366,11 @@ int bzamd_accumulate_form(void) {
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
 
+int bzamd_slow_instruction_fetch(void) {
+  if (g_state == nullptr || g_state->backend != SXT_GPU_BACKEND) return -1;
+  return msm_context_slow_instruction_fetch(g_state->context_for_current_device()) ? 1 : 0;
+}
+
 uint32_t bzamd_concurrent_calls_high_water(void) {
   return g_state == nullptr ? 0 : g_state->in_flight_high.load();
 }

@@ -20,6 +20,64 @@ const curve_vtable* curve_vtable_for(unsigned curve_id) {
   }
 }
 
+namespace {
+// Does this device fetch code that does not fit its instruction cache more slowly than it executes
+// it?  One wavefront walks a dependent chain of 8-byte v_add_u32 laid out as straight-line code, once
+// 16 KiB of it in a loop (stays in the 64 KiB cache), once 128 KiB: on one kind of MI355X box both
+// run at 3.3-3.5 ns per instruction, on the other the large body takes 6.3.  ~1.5
+// ms per device, at context creation.
+#define BZ_PROBE_ADD(v) asm volatile("v_add_u32 %0, 0x12345679, %0" : "+v"(v));
+#define BZ_R4(X) X X X X
+#define BZ_R16(X) BZ_R4(BZ_R4(X))
+#define BZ_R256(X) BZ_R16(BZ_R16(X))
+#define BZ_R2048(X) BZ_R4(BZ_R256(X)) BZ_R4(BZ_R256(X))
+template <int Blocks2048> __global__ void k_probe_code(u32* out, u32 seed, int rounds) {
+  u32 a = seed + threadIdx.x;
+  for (int r = 0; r < rounds; ++r) {
+    BZ_R2048(BZ_PROBE_ADD(a))
+    if constexpr (Blocks2048 >= 8) {
+      BZ_R2048(BZ_PROBE_ADD(a)) BZ_R2048(BZ_PROBE_ADD(a)) BZ_R2048(BZ_PROBE_ADD(a))
+      BZ_R2048(BZ_PROBE_ADD(a)) BZ_R2048(BZ_PROBE_ADD(a)) BZ_R2048(BZ_PROBE_ADD(a))
+      BZ_R2048(BZ_PROBE_ADD(a))
+    }
+  }
+  out[threadIdx.x] = a;
+}
+
+bool probe_slow_instruction_fetch() {
+  u32* d_out = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(u32) * 64) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  BZ_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  BZ_HIP_CHECK(hipEventCreate(&e0));
+  BZ_HIP_CHECK(hipEventCreate(&e1));
+  auto timed = [&](auto kernel, int rounds) {
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, d_out, 1u, 1); // load the code object, warm
+    BZ_HIP_CHECK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, d_out, 2u, rounds);
+    BZ_HIP_CHECK(hipEventRecord(e1, stream));
+    BZ_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    BZ_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return static_cast<double>(ms);
+  };
+  // the same 2^17 instructions each: 64 rounds of 2048, 8 rounds of 16384
+  (void)timed(k_probe_code<1>, 64); // clocks up
+  const double small = timed(k_probe_code<1>, 64);
+  const double large = timed(k_probe_code<8>, 8);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(stream);
+  (void)hipFree(d_out);
+  g_kernel_launches += 6;
+  return small > 0 && large > 1.4 * small;
+}
+} // namespace
+
 msm_context* msm_context_new() {
   auto* ctx = new msm_context();
   // development overrides of the sort geometry (plan.h), validated like bzamd_set_tuning: a window
@@ -75,11 +133,12 @@ msm_context* msm_context_new() {
     ctx->fuse_big = static_cast<u32>(m);
   }
   flag("BLITZAR_AMD_RANK_ONCE", ctx->rank_once);
-  if (const char* v = std::getenv("BLITZAR_AMD_COMPACT_TAILS")) {
+  if (const char* v = std::getenv("BLITZAR_AMD_COMPACT_REDUCE")) {
     const unsigned long m = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(m <= 3, "BLITZAR_AMD_COMPACT_TAILS must be 0 (off), 1 (both), 2 (horner), 3 (reduce)");
-    ctx->compact_tails = static_cast<u32>(m);
+    BZ_RELEASE_ASSERT(m <= 2, "BLITZAR_AMD_COMPACT_REDUCE must be 0 (never), 1 (always) or 2 (probe)");
+    ctx->compact_reduce = static_cast<u32>(m);
   }
+  if (ctx->compact_reduce == 2) ctx->slow_instruction_fetch = probe_slow_instruction_fetch();
   if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
     const unsigned long streams = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");
@@ -94,6 +153,7 @@ msm_context* msm_context_new() {
   return ctx;
 }
 void msm_context_free(msm_context* ctx) { delete ctx; }
+bool msm_context_slow_instruction_fetch(msm_context* ctx) { return ctx->slow_instruction_fetch; }
 void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_tasks_per_batch,
                             size_t max_workspace_bytes) {
   if (max_window_bits != 0) {

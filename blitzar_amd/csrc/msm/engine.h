@@ -206,10 +206,16 @@ struct msm_context {
   // of pass 2; larger ones are cut into chunks shared by the workers of the chunked path
   // (BLITZAR_AMD_SORT_STREAM_FACTOR, 1..16)
   u32 sort_stream_factor = 16;
-  // BLITZAR_AMD_COMPACT_TAILS: k_reduce_compact and k_horner<C, true> (the point addition at three
-  // places instead of ten / one instead of two: the code a wavefront walks fits the instruction
-  // cache) instead of the fully inlined forms
-  u32 compact_tails = 0; // 0: neither, 1: both, 2: k_horner only, 3: k_reduce only
+  // k_reduce_compact (the point addition at three places instead of ten: the code a wavefront walks
+  // fits the instruction cache) instead of k_reduce.  Measured on both kinds of MI355X boxes
+  // (profiles/round4_ab_compact_tails.log): where code beyond the instruction cache is fetched at half
+  // speed (`slow_instruction_fetch`, probed once per device at context creation) a lone k_reduce goes
+  // 0.317 -> 0.253 ms on curve25519 and 2.27 -> 1.24 ms on bls12-381 (a sequence of 2^22-row bls12-381
+  // columns 13.2 -> 12.3 ms per call); on the other kind the inlined form is faster (0.185 against
+  // 0.26), and a launch of many columns prefers it on both (its wavefronts share what they fetch).
+  // BLITZAR_AMD_COMPACT_REDUCE: 0 never, 1 always, 2 (default) where the probe and the launch say so
+  u32 compact_reduce = 2;
+  bool slow_instruction_fetch = false;
   hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
     hipStream_t s = nullptr;
     if (mask != nullptr || dedicated_queues) {
@@ -834,7 +840,10 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   if (mode.piped) ctx.acc_done[k & 3].wait(rs);
   wait_for(earlier(ctx.horner_done, 2), rs);
   ctx.timer.timed(timing, 4, rs, [&] {
-    if (ctx.compact_tails == 1 || ctx.compact_tails == 3) {
+    const bool compact = ctx.compact_reduce == 1 ||
+                         (ctx.compact_reduce == 2 && ctx.slow_instruction_fetch &&
+                          num_cols < ctx.tuning.throughput_columns);
+    if (compact) {
       hipLaunchKernelGGL((k_reduce_compact<C>), dim3(b.partial_stride, num_tasks),
                          dim3(kReduceThreads), 0, rs, b.partials, b.partial_stride, b.task_total,
                          b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
@@ -849,17 +858,10 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // ---- horner: whole columns in one launch (the range covers every window, first and last)
   if (mode.piped) ctx.reduce_done[k & 3].wait(hs);
   ctx.timer.timed(timing, 5, hs, [&] {
-    if (ctx.compact_tails == 1 || ctx.compact_tails == 2) {
-      hipLaunchKernelGGL((k_horner<C, true>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
-                         out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
-                         b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
-                         plan.reduce_segment_log2);
-    } else {
-      hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
-                         out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
-                         b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
-                         plan.reduce_segment_log2);
-    }
+    hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
+                       out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
+                       b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
+                       plan.reduce_segment_log2);
   });
   if (mode.piped) {
     ctx.horner_done[k & 3].record(hs);

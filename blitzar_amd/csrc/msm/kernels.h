@@ -1871,9 +1871,7 @@ __global__ void __launch_bounds__(kReduceThreads)
 // continues from state[column].  `last`: the range ends at window 0: write the canonical encoding
 // (or the raw projective point when `projective_out`); otherwise leave the chain value in
 // state[column].  The whole column in one launch = first && last with the full range.
-// Compact (round 4, see k_reduce_compact): the window sums through ONE addition site -- the gather
-// of a team's partials and its tree take turns in one loop -- instead of two.
-template <class C, bool Compact = false>
+template <class C>
 __global__ void __launch_bounds__(kCombineThreads)
     k_horner(u8* __restrict__ out, u32 out_stride, int projective_out,
              typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
@@ -1921,47 +1919,16 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 reduce_block = kReduceThreads << reduce_seg_log2; // buckets per k_reduce block
   const u32 blocks = (nb + reduce_block - 1) / reduce_block;
   point sum = C::identity();
-  if constexpr (Compact) {
-    // steps: ceil(blocks / team) gathers (a lane publishes its next partial for itself), then the
-    // tree over the team (a lane publishes its sum for the lane `stride` below)
-    const point* p = partials + static_cast<u64>(col.first_task + w_lo + (w < W ? w : 0)) * partial_stride;
-    const u32 gathers = (blocks + team - 1) / team;
-    u32 tree_steps = 0;
-    while ((1u << tree_steps) < team) ++tree_steps;
-    for (u32 step = 0; step < gathers + tree_steps; ++step) {
-      bool act;
-      u32 src = tid;
-      point publish = sum;
-      if (step < gathers) {
-        const u32 blk = lane + step * team;
-        act = w < W && blk < blocks;
-        if (act) publish = p[blk];
-      } else {
-        const u32 stride = (team / 2) >> (step - gathers);
-        act = w < W && lane < stride;
-        if (act) src = tid + stride;
-      }
-      tree[tid] = publish;
-      __syncthreads();
-      const point other = tree[src];
-      const point sum_out = C::add(sum, other);
-      if (act) sum = sum_out;
-      __syncthreads();
-    }
-    tree[tid] = sum;
+  if (w < W && lane < blocks) {
+    const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;
+    sum = p[lane];
+    for (u32 blk = lane + team; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
+  }
+  tree[tid] = sum;
+  __syncthreads();
+  for (u32 stride = team / 2; stride > 0; stride >>= 1) {
+    if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
     __syncthreads();
-  } else {
-    if (w < W && lane < blocks) {
-      const point* p = partials + static_cast<u64>(col.first_task + w_lo + w) * partial_stride;
-      sum = p[lane];
-      for (u32 blk = lane + team; blk < blocks; blk += team) sum = C::add(sum, p[blk]);
-    }
-    tree[tid] = sum;
-    __syncthreads();
-    for (u32 stride = team / 2; stride > 0; stride >>= 1) {
-      if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
-      __syncthreads();
-    }
   }
   // all lanes of the first wavefront run the chain: keeping the data in vector registers stops
   // hipcc from moving the multi-limb chain onto the scalar unit (it did: s_mul_hi_u32 chains with

@@ -67,6 +67,10 @@ uint64_t bzamd_kernel_launch_count(void);
  * take per-device leases, not a process-wide lock: two host threads on a two-device backend run
  * side by side; tests use this to prove it) */
 uint32_t bzamd_concurrent_calls_high_water(void);
+/* 1 if the current device fetches code beyond its instruction cache more slowly than it executes it
+ * (probed once per device; such devices run the bucket reduction of calls with few columns through
+ * k_reduce_compact), 0 if not, -1 without an initialised GPU backend */
+int bzamd_slow_instruction_fetch(void);
 /* drop the backend singleton so that sxt_init may be called again (reference:
  * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
 void bzamd_reset_for_testing(void);
