@@ -68,6 +68,9 @@ def parse_args():
                     help="profiling runs: keep the oracle for the configs legs but skip the 16 s "
                          "reference-CPU run on the headline column (no `verified`, no cpu_baseline)")
     ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--no-aux", action="store_true",
+                    help="profiling runs: skip the device_state legs (3000 extra calls) and the "
+                         "host_api child processes")
     ap.add_argument("--dry-run-one-gpu", action="store_true",
                     help="self-test of the N > 1 control flow on a one-GPU box: every rank uses "
                          "cuda:0 and the collectives go through gloo on host copies (never a "
@@ -980,7 +983,7 @@ def main():
             result["roofline"] = roof
         if cpu is not None and world == 1:
             result["cpu_baseline"] = cpu
-        if world == 1 and not args.no_configs and args.log2n is None:
+        if world == 1 and not args.no_configs and args.log2n is None and not args.no_aux:
             try:
                 result["device_state"] = device_state(
                     lib, lambda: lib.bzamd_msm_device(curve_id, vp(outs[0:1]), 1, desc,
@@ -989,6 +992,7 @@ def main():
                     stream)
             except Exception as exc:  # never at the price of the line
                 result["device_state"] = {"error": repr(exc)[:300]}
+        if world == 1 and not args.no_configs and args.log2n is None:
             result["configs"] = run_configs(lib, oracle, args, dev, stream)
         if sharded is not None:
             result["configs"] = [sharded]
@@ -1014,7 +1018,7 @@ def main():
         # the 570 MB librccl for that costs up to a minute on a fresh box)
         if not args.no_configs and not args.dry_run_one_gpu and torch.cuda.device_count() > 1:
             result["in_process_multi_device"] = in_process_multi_device()
-        if world == 1 and not args.no_configs and args.log2n is None:
+        if world == 1 and not args.no_configs and args.log2n is None and not args.no_aux:
             result["host_api"] = host_api()
         print(json.dumps(result), flush=True)
 
