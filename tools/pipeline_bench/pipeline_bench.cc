@@ -43,7 +43,7 @@ static double now_ms() {
 
 int main(int argc, char** argv) {
   unsigned curve = 0, log2n = 20, columns = 1, steps = 200, warmup = 10, nbytes = 32;
-  bool null_stream = false, resident = false, skew = false;
+  bool null_stream = false, resident = false, skew = false, no_mask = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&] { return static_cast<unsigned>(std::atoi(argv[++i])); };
@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
     else if (a == "--null-stream") null_stream = true;
     else if (a == "--resident") resident = true;
     else if (a == "--skew") skew = true;
+    else if (a == "--no-mask") no_mask = true; // full 256-bit scalars: the top window is as full as the others
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());
       return 2;
@@ -76,7 +77,7 @@ int main(int argc, char** argv) {
     const uint64_t v = x * 0x2545f4914f6cdd1dull;
     std::memcpy(&host[i], &v, 8);
   }
-  if (nbytes == 32) {
+  if (nbytes == 32 && !no_mask) {
     for (size_t r = 0; r < static_cast<size_t>(columns) * n; ++r) host[r * 32 + 31] &= 0x0f;
   }
   if (skew) {
