@@ -91,3 +91,10 @@ def test_homomorphism(cpu_backend):
     out = cpu_backend.compute_pedersen_commitments(0, [(a, False), (b, False), (wide, False)])
     pa, pb = hooks.ristretto_decode(out[0]), hooks.ristretto_decode(out[1])
     assert np.array_equal(hooks.ristretto_encode(hooks.ed_add(pa, pb)), out[2])
+
+
+def test_gpu_only_queries_answer_on_the_host_backend(cpu_backend):
+    """the device queries of include/blitzar_amd.h have defined answers without a GPU backend"""
+    lib = cpu_backend.load()
+    assert lib.bzamd_slow_instruction_fetch() == -1
+    assert lib.bzamd_concurrent_calls_high_water() == 0
