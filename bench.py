@@ -68,6 +68,8 @@ def parse_args():
                     help="profiling runs: keep the oracle for the configs legs but skip the 16 s "
                          "reference-CPU run on the headline column (no `verified`, no cpu_baseline)")
     ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--arrangement", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="pin the throughput mode's arrangement instead of keeping the best measured")
     ap.add_argument("--no-aux", action="store_true",
                     help="profiling runs: skip the device_state legs (3000 extra calls) and the "
                          "host_api child processes")
@@ -800,20 +802,47 @@ def main():
             step(0)
         finish()
         torch.cuda.synchronize()
-        # one sequence; the clock (two events on the caller's stream) starts behind its 30th call:
-        # the device comes out of the allocation gap above at reduced clocks
         calls = max(args.steps, 50)
         begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for k in range(30 + calls):
-            if k == 30:
-                begin.record()
-            step(k % max_steps)
-        finish()
-        end.record()
-        torch.cuda.synchronize()
-        legs["sustained_ms"] = begin.elapsed_time(end) / calls
+
+        def sustained():
+            # one sequence; the clock (two events on the caller's stream) starts behind its 30th call:
+            # the device comes out of an idle gap at reduced clocks
+            for k in range(30 + calls):
+                if k == 30:
+                    begin.record()
+                step(k % max_steps)
+            finish()
+            end.record()
+            torch.cuda.synchronize()
+            legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 30 + calls
+            return begin.elapsed_time(end) / calls
+
+        # Where the front of a pipelined call runs (include/blitzar_amd.h, bzamd_pipeline_arrangement):
+        # on the caller's stream (0) or on an internal stream beside the previous call's accumulation
+        # (1..3).  Which is fastest depends on how THIS process's streams share the device's hardware
+        # queues -- under torch's stream pool the split arrangements gain 3-4 %, in a process with one
+        # stream they lose 2-25 % (profiles/round4_front_arrangements.txt) -- so the bench measures all
+        # four here, untimed, and keeps the best for the warmup and the timed region.
+        measured = {}
+        for arrangement in (0, 1, 2, 3):
+            lib.bzamd_pipeline_arrangement(arrangement)
+            measured[arrangement] = sustained()
+        best = min(measured, key=measured.get)
+        if args.arrangement is not None:
+            best = args.arrangement
+        lib.bzamd_pipeline_arrangement(best)
+        legs["arrangement"] = {"chosen": best,
+                               "sustained_ms_per_step": {str(a): round(v, 4) for a, v in measured.items()},
+                               "meaning": "0: the front of a call on the caller's stream; 1-3: on an "
+                                          "internal stream beside the previous call's accumulation "
+                                          "(1: high-priority front stream + a dedicated accumulation "
+                                          "queue, 2: two plain streams, 3: high-priority front stream "
+                                          "+ a plain accumulation stream); measured untimed, the "
+                                          "best kept for the warmup and the timed region"}
+        legs["sustained_ms"] = sustained()
         legs["sustained_calls"] = calls
-        legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 2 + 30 + calls
+        legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 2
 
     # Order.  The device idles at ~100 MHz and comes back slowly: after ANY idle gap (20 ms are
     # enough) the first calls of a sequence take 1.14, 1.11, 1.06, 1.03, 1.00, 0.98 ms ... and the
@@ -849,6 +878,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed_stages, calls = clock.collect(args.steps)
+    lib.bzamd_pipeline_arrangement(0)  # the configs legs below run in the default arrangement
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
@@ -940,6 +970,7 @@ def main():
             "single_call_ms": single_call_ms,
             "sustained_ms_per_step": legs["sustained_ms"],
             "sustained_steps": legs["sustained_calls"],
+            "pipeline_arrangement": legs["arrangement"],
             "mode": "throughput mode of the library (bzamd_pipeline_next / bzamd_pipeline_flush): the "
                     "last stage of step k (one workgroup per column) runs beside the front of step "
                     "k + 1; all K commitments are complete, and the last one verified, inside the "

@@ -182,6 +182,25 @@ void msm_context_set_window_bits(msm_context* ctx, u32 window_bits) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->tuning.force_window_bits = window_bits;
 }
+void msm_context_set_arrangement(msm_context* ctx, u32 arrangement) {
+  BZ_RELEASE_ASSERT(arrangement <= 3, "throughput-mode arrangement must be 0..3");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  BZ_RELEASE_ASSERT(!ctx->any_pending(),
+                    "flush the throughput mode (bzamd_pipeline_flush) before changing its arrangement");
+  // the front / accumulation streams are made for an arrangement: drop the old pair (idle: nothing is
+  // pending), the next pipelined call creates what the new arrangement needs
+  for (hipStream_t* s : {&ctx->front, &ctx->acc}) {
+    if (*s != nullptr) {
+      BZ_HIP_CHECK(hipStreamSynchronize(*s));
+      BZ_HIP_CHECK(hipStreamDestroy(*s));
+      *s = nullptr;
+    }
+  }
+  ctx->overlap_front = arrangement != 0;
+  ctx->front_high_priority = arrangement == 1 || arrangement == 3;
+  ctx->dedicated_queues = arrangement == 1;
+  ctx->front_cus = 0;
+}
 void msm_context_defer_next_tail(msm_context* ctx) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->defer_tail = true;

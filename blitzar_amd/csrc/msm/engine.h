@@ -165,7 +165,6 @@ struct msm_context {
   // BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.  A lone call never forks (every
   // fork / join pair costs ~25 us of stream bubbles).
   hipStream_t front = nullptr, acc = nullptr, tail = nullptr, tail2 = nullptr;
-  bool pipe_streams_made = false;
   stage_mark entry;
   stage_mark front_done[4], acc_done[4], reduce_done[4], horner_done[4];
   u64 seq = 0;            // pipelined batches enqueued so far on this context
@@ -245,9 +244,9 @@ struct msm_context {
       BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail, hipStreamNonBlocking, priority));
       BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail2, hipStreamNonBlocking, priority));
     }
-    if (pipe_streams_made || null_caller) return;
-    pipe_streams_made = true;
-    if (!overlap_front) return;
+    // (the front / accumulation streams exist once the arrangement that uses them has been asked
+    // for: by the environment at context creation or by msm_context_set_overlap_front later)
+    if (null_caller || !overlap_front || front != nullptr) return;
     int device = 0, cus = 0;
     BZ_HIP_CHECK(hipGetDevice(&device));
     BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
