@@ -69,7 +69,11 @@ def parse_args():
                          "reference-CPU run on the headline column (no `verified`, no cpu_baseline)")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--arrangement", type=int, default=None, choices=[0, 1, 2, 3],
-                    help="pin the throughput mode's arrangement instead of keeping the best measured")
+                    help="run the throughput mode in this arrangement (bzamd_pipeline_arrangement) "
+                         "instead of the library's default (0)")
+    ap.add_argument("--search-arrangements", action="store_true",
+                    help="measure the arrangements 1..3 (three stream layouts each), untimed, and keep "
+                         "the first one 3 %% faster than the default; one rank only")
     ap.add_argument("--no-aux", action="store_true",
                     help="profiling runs: skip the device_state legs (3000 extra calls) and the "
                          "host_api child processes")
@@ -168,9 +172,11 @@ def timed_calls(lib, fn, steps, warmup, stream):
     return dt, stages
 
 
-def lone_calls(fn, calls=3):
+def lone_calls(fn, calls=3, lib=None):
     """ms of a lone call with plain stream semantics (no throughput mode): each call is followed by
-    a device synchronisation; the minimum and the mean over `calls` calls after one untimed call"""
+    a device synchronisation; the minimum and the mean over `calls` calls after one untimed call.
+    With `lib`: one more lone call under the engine's stage clock -- a lone call runs its six
+    stages one after the other on the caller's stream, so these spans DO add up"""
     fn()
     torch.cuda.synchronize()
     ms = []
@@ -179,7 +185,14 @@ def lone_calls(fn, calls=3):
         fn()
         torch.cuda.synchronize()
         ms.append(1e3 * (time.perf_counter() - t0))
-    return {"min": min(ms), "mean": sum(ms) / len(ms), "calls": calls}
+    out = {"min": min(ms), "mean": sum(ms) / len(ms), "calls": calls}
+    if lib is not None:
+        clock = StageClock(lib, 64)
+        fn()
+        torch.cuda.synchronize()
+        stages, _ = clock.collect(1)
+        out["stages"] = {k: round(v, 4) for k, v in stages.items()}
+    return out
 
 
 STAGE_NOTE = ("stage times of calls IN A SEQUENCE: HIP-event spans on the stream each stage runs on; "
@@ -303,7 +316,7 @@ def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps,
 
     dt, stages = timed_calls(lib, step, steps, 1, stream)
     got = out.cpu().numpy()
-    lone = lone_calls(step)
+    lone = lone_calls(step, lib=lib)
     bad = []
     for c in range(columns):
         sums = wl.weighted_byte_sums(scalars[c])
@@ -316,6 +329,7 @@ def variable_base_config(lib, oracle, cid, name, log2n, columns, scalars, steps,
     alg_bytes = ops * 32 + n * stride + columns * api.CURVE_LAYOUT[cid][1]
     entry = {"config": name, "rows": n, "columns": columns, "ms_per_call": dt * 1e3,
              "lone_call_ms": round(lone["min"], 4), "lone_call_ms_mean": round(lone["mean"], 4),
+             "lone_call_stage_ms": lone["stages"],
              "scalar_point_ops_per_s": ops / dt, "commitments_per_s": columns / dt,
              "stage_ms_per_call": {k: round(v, 4) for k, v in stages.items()},
              "stage_ms_note": STAGE_NOTE,
@@ -819,23 +833,28 @@ def main():
             return begin.elapsed_time(end) / calls
 
         # Where the front of a pipelined call runs (include/blitzar_amd.h, bzamd_pipeline_arrangement):
-        # on the caller's stream (0) or on an internal stream beside the previous call's accumulation
-        # (1..3).  Which is fastest depends on how THIS process's streams share the device's hardware
-        # queues -- under torch's stream pool the split arrangements gain 3-4 %, in a process with one
-        # stream they lose 2-25 % (profiles/round4_front_arrangements.txt) -- so the bench measures all
-        # four here, untimed, and keeps the best for the warmup and the timed region.
-        baseline = min(sustained(), sustained())  # arrangement 0, the library's default
+        # on the caller's stream (0, the library's default and what this line measures) or on an
+        # internal stream beside the previous call's accumulation (1..3).  Which is fastest depends on
+        # how the process's streams share the device's hardware queues: in a small torch script the
+        # split arrangements gain 3-4 %, in a process with one stream they lose 2-25 %
+        # (profiles/round4_front_arrangements.txt), and in THIS process a walk through three stream
+        # layouts per arrangement found 0.931-0.943 once and 1.00-1.08 otherwise against 0.954-0.956
+        # for the default (profiles/round4_arrangement_search.json): nothing to keep.  The walk stays
+        # behind --search-arrangements (one rank only), --arrangement pins one.
+        baseline = sustained()  # arrangement 0
         tried = [{"arrangement": 0, "ms": round(baseline, 4)}]
         best = 0
         if args.arrangement is not None:
             best = args.arrangement
             lib.bzamd_pipeline_arrangement(best)
-        else:
+        elif args.search_arrangements and world == 1:
             # every call of bzamd_pipeline_arrangement makes a NEW pair of internal streams, which the
             # runtime binds to the next hardware queues in its rotation: a few attempts per
             # arrangement walk through the layouts this process can get.  The first layout that is
             # 3 % faster than the default is kept as it stands (its streams are not touched again);
             # if none is, the default stays.
+            baseline = min(baseline, sustained())
+            tried[0]["ms"] = round(baseline, 4)
             for arrangement, attempt in [(a, t) for t in range(3) for a in (2, 1, 3)]:
                 lib.bzamd_pipeline_arrangement(arrangement)
                 ms = sustained()
@@ -852,8 +871,8 @@ def main():
                                           "dedicated accumulation queue, 2: two plain streams, 3: "
                                           "high-priority front stream + a plain accumulation stream); "
                                           "`tried`: sustained ms per step of every layout measured, "
-                                          "untimed; the first one 3 % faster than the default is kept "
-                                          "for the warmup and the timed region"}
+                                          "untimed (more than the default only under "
+                                          "--search-arrangements / --arrangement)"}
         legs["sustained_ms"] = sustained()
         legs["sustained_calls"] = calls
         legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 2
@@ -892,7 +911,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed_stages, calls = clock.collect(args.steps)
-    lib.bzamd_pipeline_arrangement(0)  # the configs legs below run in the default arrangement
+    if legs["arrangement"]["chosen"] != 0:
+        lib.bzamd_pipeline_arrangement(0)  # the configs legs below run in the default arrangement
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
