@@ -43,6 +43,7 @@ template <class P> struct sw29 {
   using point = sw29_point<N>;
   using affine = sw29_affine<N>;
   static constexpr bool b3_negative = P::b3_negative;
+  static constexpr u32 b3_abs = P::b3_abs;
 
   BZ_HD static point identity() { return {F::zero(), F::one(), F::zero()}; }
 

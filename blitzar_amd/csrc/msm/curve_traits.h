@@ -11,6 +11,7 @@
 #include "blitzar_amd/csrc/curve/ed16_wave.h"
 #include "blitzar_amd/csrc/curve/sw29.h"
 #include "blitzar_amd/csrc/curve/sw29_coop.h"
+#include "blitzar_amd/csrc/curve/sw_wave.h"
 #include "blitzar_amd/csrc/curve/weierstrass.h"
 
 namespace bz {
@@ -175,6 +176,7 @@ struct ed25519_msm {
   // canonical encoding by a whole wavefront (every lane passes the same point, lane 0 writes): the
   // inverse square root's 252 squarings run lane-parallel
   static constexpr bool has_wave_encode = true;
+  static constexpr bool has_coop_add = false;
   __device__ static void wave_encode(u8* out, const point& p) {
     const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
     u64 w[4];
@@ -266,12 +268,21 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr bool has_signed_gather = false;
   static constexpr bool has_wave_encode = false;
   static constexpr bool has_wave_add_multiple = false;
-  // k_horner's dependent chain on one wavefront: doublings split over the lanes of each DPP quad
-  // (curve/sw29_coop.h), the one addition per window computed redundantly by every lane
+  // k_horner's dependent chain on one wavefront: the point spread over the wavefront, limb j of a
+  // coordinate in lane j of a DPP row, four field products at once (curve/sw_wave.h).
+  // BZ_SW_WAVE_HORNER=0: the form of rounds 2-3 -- doublings split over the lanes of each DPP quad
+  // (curve/sw29_coop.h), the one addition per window computed redundantly by every lane.
+#ifndef BZ_SW_WAVE_HORNER
+#define BZ_SW_WAVE_HORNER 1
+#endif
   static constexpr bool has_wave_horner = true;
 #if defined(__HIPCC__)
   __device__ static point wave_horner(point acc, bool have_acc, point* window_sums,
                                       u32 stride, u32 num_windows, u32 window_bits) {
+#if BZ_SW_WAVE_HORNER
+    return sww::wave<G29>::horner(sww::wave_scratch(), acc, have_acc, window_sums, stride,
+                                  num_windows, window_bits);
+#else
     const u32 role = threadIdx.x & 3;
     u32 i = num_windows;
     if (!have_acc) {
@@ -283,6 +294,15 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
       acc = G29::add(acc, window_sums[i * stride]);
     }
     return acc;
+#endif
+  }
+#endif
+
+  // k_horner's window fold: an addition split over the four lanes of a DPP quad (curve/sw29_coop.h)
+  static constexpr bool has_coop_add = true;
+#if defined(__HIPCC__)
+  __device__ static point add_coop4(const point& a, const point& b, u32 role) {
+    return sw29_coop::add_coop4<G29>(a, b, role);
   }
 #endif
 

@@ -1927,6 +1927,21 @@ __global__ void __launch_bounds__(kCombineThreads)
   tree[tid] = sum;
   __syncthreads();
   for (u32 stride = team / 2; stride > 0; stride >>= 1) {
+    if constexpr (C::has_coop_add) {
+      // a level with at most one addition per quad of the workgroup: the four lanes of a DPP quad
+      // share each addition (the latency of ~4 field products instead of 12; on the Weierstrass
+      // curves the fold is a third of a lone k_horner)
+      if (W * stride * 4 <= kCombineThreads) {
+        const u32 a = tid >> 2;
+        if (a < W * stride) {
+          const u32 e = (a / stride) * team + a % stride;
+          const point sum2 = C::add_coop4(tree[e], tree[e + stride], tid & 3);
+          if ((tid & 3) == 0) tree[e] = sum2;
+        }
+        __syncthreads();
+        continue;
+      }
+    }
     if (w < W && lane < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
     __syncthreads();
   }

@@ -376,7 +376,19 @@ def test_mont29_field_matches_reference(oracle, cid):
                                              f.ctypes.data_as(ctypes.c_void_p),
                                              g.ctypes.data_as(ctypes.c_void_p))
         assert np.array_equal(hooks.sw29_field(cid, "mul", f, g), want)
-    for f in elems[:6]:
+    # the inversion (field/mont29.h: Kaliski's almost inverse with bulk shifts): random elements and
+    # the ones that stress its shifts -- powers of two (long runs of trailing zeros, whole zero
+    # words), 1, p - 1, small odd values
+    special = [one]
+    for bit in (1, 63, 64, 65, 127, 128, 200, 64 * nl - 4):
+        w = np.zeros(nl, np.uint64)
+        w[bit // 64] = np.uint64(1) << np.uint64(bit % 64)
+        special.append(w)            # Montgomery form of some element: any canonical value < p
+    for small in (2, 3, 5, 0xffffffffffffffff):
+        w = np.zeros(nl, np.uint64)
+        w[0] = np.uint64(small)
+        special.append(w)
+    for f in list(elems[:38]) + special:
         inv = hooks.sw29_field(cid, "invert", f)
         assert np.array_equal(hooks.sw29_field(cid, "mul", f, inv), one)
     # mul2: (2a) b + c (3d) with ONE Montgomery reduction == 2 ab + 3 cd
