@@ -159,6 +159,7 @@ struct ed25519_msm {
   }
   // v + m * s (m != 0) by a whole wavefront: every lane passes the same points and m
   static constexpr bool has_wave_add_multiple = true;
+  static constexpr bool reduce_scan_few_columns_only = false;
   __device__ static point wave_add_multiple(const point& v, const point& s, u32 m) {
     __shared__ ed29_cached_packed addend[2];
     const ed16w::lane_ctx c = ed16w::make_ctx(ed16w::wave_scratch());
@@ -267,7 +268,30 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr bool has_batched_prepare = false;
   static constexpr bool has_signed_gather = false;
   static constexpr bool has_wave_encode = false;
-  static constexpr bool has_wave_add_multiple = false;
+  // k_reduce's lane weights as a suffix scan over the lanes (8 additions per lane instead of a
+  // 15-bit double-and-add); the one multiple left per workgroup -- the block's first bucket index
+  // times the block's plain sum -- by a whole wavefront on the lane-spread form (curve/sw_wave.h).
+  // BZ_SW_REDUCE_SCAN=0: the per-lane double-and-add of rounds 1-3.
+#ifndef BZ_SW_REDUCE_SCAN
+#define BZ_SW_REDUCE_SCAN 1
+#endif
+  static constexpr bool has_wave_add_multiple = BZ_SW_REDUCE_SCAN != 0;
+  // only for launches of few columns (engine.h; see k_reduce): many columns keep the per-lane form
+  static constexpr bool reduce_scan_few_columns_only = true;
+#if defined(__HIPCC__)
+  // v + m * s (m != 0) by a whole wavefront: every lane passes the same points and m
+  __device__ static point wave_add_multiple(const point& v, const point& s, u32 m) {
+    using W = sww::wave<G29>;
+    const typename W::ctx c = W::make_ctx(sww::wave_scratch());
+    const u32 sq = W::load_point_value(c, s), vq = W::load_point_value(c, v);
+    u32 st = sq;
+    for (int bit = 30 - __builtin_clz(m); bit >= 0; --bit) {
+      st = W::dbl(c, st);
+      if ((m >> bit) & 1) st = W::add(c, st, sq);
+    }
+    return W::store_point(c, W::add(c, st, vq));
+  }
+#endif
   // k_horner's dependent chain on one wavefront: the point spread over the wavefront, limb j of a
   // coordinate in lane j of a DPP row, four field products at once (curve/sw_wave.h).
   // BZ_SW_WAVE_HORNER=0: the form of rounds 2-3 -- doublings split over the lanes of each DPP quad

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "blitzar_amd/csrc/base/device.h"
@@ -847,9 +848,20 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                          dim3(kReduceThreads), 0, rs, b.partials, b.partial_stride, b.task_total,
                          b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
     } else {
-      hipLaunchKernelGGL((k_reduce<C>), dim3(b.partial_stride, num_tasks), dim3(kReduceThreads), 0,
-                         rs, b.partials, b.partial_stride, b.task_total, b.bucket_sums, b.heads,
-                         b.bucket_end, b.tasks, plan.reduce_segment_log2);
+      auto launch = [&](auto scan) {
+        hipLaunchKernelGGL((k_reduce<C, decltype(scan)::value>), dim3(b.partial_stride, num_tasks),
+                           dim3(kReduceThreads), 0, rs, b.partials, b.partial_stride, b.task_total,
+                           b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
+      };
+      if constexpr (!C::has_wave_add_multiple) {
+        launch(std::false_type{});
+      } else if constexpr (!C::reduce_scan_few_columns_only) {
+        launch(std::true_type{});
+      } else if (num_cols < ctx.tuning.throughput_columns) {
+        launch(std::true_type{});
+      } else {
+        launch(std::false_type{});
+      }
     }
   });
   if (mode.piped) ctx.reduce_done[k & 3].record(rs);

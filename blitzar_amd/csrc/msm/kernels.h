@@ -1433,7 +1433,13 @@ __device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end, u32 seg_log
 // the front of the next call would run faster beside it: it did not, and the 9-limb Weierstrass
 // curves went from 209 to 284 registers, one wavefront per SIMD instead of two, config 4's
 // k_reduce 33.0 -> 42.6 ms.  Reverted: profiles/round3_ab_reduce_lds.log.)
-template <class C>
+// Scan: the lane weights as a suffix scan over the lanes + one multiple per workgroup
+// (C::wave_add_multiple) instead of a double-and-add per lane.  curve25519: always.  Weierstrass
+// curves: for launches of few columns, where it is the shorter chain (a lone bls12-381 k_reduce
+// 0.82 -> 0.73 ms); a launch of many columns is bound by issue slots and barriers, not by the
+// length of a lane's chain, and runs 30-60 % LONGER under the scan (config 4: 32.7 -> 42.6 ms,
+// config 5: 13.7 -> 22.0, profiles/round4_ab_weierstrass_tails.txt)
+template <class C, bool Scan>
 __global__ void __launch_bounds__(kReduceThreads)
     k_reduce(typename C::point* __restrict__ partials, u32 partial_stride,
              u32* __restrict__ task_total, const typename C::point* __restrict__ bucket_sums,
@@ -1537,7 +1543,7 @@ __global__ void __launch_bounds__(kReduceThreads)
       }
     }
   }
-  if constexpr (C::has_wave_add_multiple) {
+  if constexpr (Scan) {
     // inclusive suffix scan of s over the 256 lanes
     point x = s;
     for (u32 d = 1; d < kReduceThreads; d <<= 1) {
