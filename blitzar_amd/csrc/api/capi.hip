@@ -331,56 +331,91 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
 // wherever the longest column has at least k rows (tests)
 std::atomic<u32> g_row_pipeline_chunks{0};
 
-// How many row chunks a single-device call with host operands is cut into.  The upload of a call
-// runs at the link's rate whatever we do (measured on the MI355X boxes: hipMemcpyAsync from pageable
-// memory 56.5 GB/s, from pinned memory 57.5 -- profiles/round4_h2d_rates.txt), so what a call can gain
-// is overlap: chunk k computes while chunk k + 1 uploads, and only the smaller of the two sides
-// stays exposed, 1 / chunks of it.  Chunks cost work (every chunk reduces its own buckets and runs
-// its own Horner chain; short columns take narrower windows), so compute-bound shapes take few.
-u32 choose_row_chunks(const curve_vtable& vt, const std::vector<host_column>& cols, u64 longest,
-                      bool uploads_generators) {
+// How many row chunks a single-device call with host operands is cut into, and how many of its
+// columns take part in them (`lead`; the others follow as whole columns).  The upload of a call runs
+// at the link's rate whatever we do (measured on the MI355X boxes: hipMemcpyAsync from pageable memory
+// 56.5 GB/s, from pinned memory 57.5 -- profiles/round4_h2d_rates.txt), so what a call can gain is
+// overlap: chunk k computes while chunk k + 1 uploads.  Chunks cost work -- every chunk of every
+// column reduces its own buckets and runs its own Horner chain -- so only as many columns are cut
+// as it takes to keep the device busy while the caller's generators arrive.
+struct row_pipeline_shape {
+  u32 chunks = 1;
+  u32 lead = 0;
+};
+row_pipeline_shape choose_row_chunks(const curve_vtable& vt, const std::vector<host_column>& cols,
+                                     u64 longest, bool uploads_generators) {
+  const u32 num_cols = static_cast<u32>(cols.size());
   const u32 forced = g_row_pipeline_chunks.load();
-  if (forced != 0) return static_cast<u32>(std::min<u64>(forced, std::max<u64>(longest, 1)));
-  // Measured on MI355X (profiles/round4_hostapi_chunks.txt, curve25519, 2^20 rows): the pipeline pays
-  // where the caller's generators dominate the upload -- one or two columns: 160 bytes of generator
-  // against 32 bytes of scalar per row and column -- and nothing of the call can start before they
-  // are all there.  Calls with many columns already overlap their column chunks with the upload
-  // (enqueue_commitments), and a call on resident generators uploads too little for chunks to
-  // recover what they cost (8 chunks: 1.78 -> 2.96 ms).
+  if (forced != 0) {
+    return {static_cast<u32>(std::min<u64>(forced, std::max<u64>(longest, 1))),
+            uploads_generators ? std::min(4u, num_cols) : num_cols};
+  }
+  // Measured on MI355X (profiles/round4_hostapi_chunks*.txt, round4_hostapi_timeline_*.txt;
+  // curve25519, 2^20 rows): the pipeline pays where the caller's generators dominate the upload --
+  // 160 bytes of generator against 32 bytes of scalar per row and column -- and nothing of the call
+  // could start before they are all there.  The first four columns are committed chunk by chunk
+  // while the generators stream in (a chunk's converted addends stay: one full set is resident when
+  // the last chunk is through), the other columns follow whole, overlapping their own uploads as in
+  // enqueue_commitments.  One column of 2^20 rows: 4.86 ms unpipelined, 4.65 in 8 chunks; two: 6.38 ->
+  // 5.45; ten: 14.46 unpipelined, 13.97 / 14.00 / 13.28 / 13.44 / 14.80 with 2 / 3 / 4 / 6 / 10 lead
+  // columns (every chunk of every lead column reduces its own buckets: more of them cost more than the
+  // idle device they fill).  A call on resident generators uploads too little for chunks to recover
+  // what they cost (8 chunks: 1.78 -> 2.96 ms).
   (void)vt;
-  if (!uploads_generators || cols.size() > 2 || longest < (u64{1} << 19)) return 1;
-  return 8; // one column of 2^20 rows: 4.86 ms unpipelined, 4.68 in 4 chunks, 4.64 in 8; two: 6.38 / 5.55 / 5.45
+  if (!uploads_generators || longest < (u64{1} << 19)) return {1, 0};
+  // BLITZAR_AMD_ROW_PIPELINE_LEAD: the number of lead columns (A/B runs)
+  static const u32 lead_columns = [] {
+    const char* e = std::getenv("BLITZAR_AMD_ROW_PIPELINE_LEAD");
+    const long v = e != nullptr ? std::atol(e) : 0;
+    return v >= 1 && v <= 64 ? static_cast<u32>(v) : 4u;
+  }();
+  return {8, std::min(lead_columns, num_cols)};
 }
 
-// The same commitment as enqueue_commitments, as a pipeline over `chunks` row ranges: the copy
-// stream uploads range k + 1 (the caller's generators of the range and every column's rows) into
-// the other of two staging regions while the engine commits range k to projective partials (in
-// throughput mode: the tails of range k run beside the front of range k + 1); one fold kernel adds
-// the partials up and encodes.  Group addition is exact: the commitments are the same bytes.
+// The same commitments as enqueue_commitments, as a pipeline over `chunks` row ranges for the first
+// `lead` columns: a host thread uploads range k + 1 -- the caller's generators of the range, then the
+// lead columns' rows of it -- while the engine converts the generators of range k into their slice of
+// ONE full addend array and commits the lead columns' rows of range k to projective partials
+// (throughput mode: the tails of range k run beside the front of range k + 1).  The columns after the
+// lead follow whole on the complete addend array, their uploads overlapping the computation before
+// them; one fold kernel adds the lead columns' partials up and encodes.  Group addition is exact: the
+// commitments are the same bytes.
+// (ONE upload thread and copy stream: with the generators and the rows on a thread and a stream each
+// the link has no idle gaps, but every memory-bound kernel that runs beside TWO copies in flight takes
+// 3-4x as long -- k_recode 9 -> 50 us, k_group_scatter 26 -> 109, k_prepare_addends 15 -> 113 -- and a
+// one-column call went from 4.65 to 7.2 ms: profiles/round4_hostapi_timeline_*_two_upload_threads.txt.)
 u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curve_vtable& vt,
                                      const std::vector<host_column>& cols, u64 longest,
                                      const generator_ref& gens, u32 out_stride, bool projective_out,
-                                     u32 chunks, std::vector<hipEvent_t>& events) {
+                                     row_pipeline_shape shape, std::vector<hipEvent_t>& events) {
   ds.activate();
   const bool upload_generators = gens.source == generator_source::host_api;
   const u32 num_sequences = static_cast<u32>(cols.size());
+  const u32 chunks = shape.chunks;
+  const u32 lead = std::max(1u, std::min(shape.lead, num_sequences));
+  const std::vector<host_column> lead_cols(cols.begin(), cols.begin() + lead);
+  std::vector<host_column> rest_cols(cols.begin() + lead, cols.end());
   const u32 psize = static_cast<u32>(vt.projective_size);
   const u64 rows_max = (longest + chunks - 1) / chunks + 1;
   // staging regions in rotation: the upload of chunk k waits for the computation of chunk
   // k - kRegions only (with two regions it kept running into the computation of chunk k - 2, which
   // shares the device with the upload of chunk k - 1)
   constexpr u32 kRegions = 3;
-  // one staging region: [caller generators | addends] + every column's rows of a range
+  // one staging region: the caller's generators of a range + the lead columns' rows of it
   size_t region_bytes = 0;
-  if (upload_generators) {
-    region_bytes += device_arena::padded(vt.api_generator_size * rows_max + 32) +
-                    device_arena::padded(vt.addend_size * (rows_max + 1));
-  }
-  for (const auto& c : cols) {
+  if (upload_generators) region_bytes += device_arena::padded(vt.api_generator_size * rows_max + 32);
+  for (const auto& c : lead_cols) {
     region_bytes += device_arena::padded(static_cast<size_t>(std::min<u64>(c.n, rows_max)) * c.row_stride + 32);
   }
-  const size_t partial_bytes = static_cast<size_t>(psize) * num_sequences;
-  ds.io.reset(kRegions * region_bytes + device_arena::padded(partial_bytes * chunks) +
+  size_t rest_bytes = 0;
+  for (const auto& c : rest_cols) {
+    rest_bytes += device_arena::padded(static_cast<size_t>(c.n) * c.row_stride + 32);
+  }
+  const size_t addend_bytes =
+      upload_generators ? device_arena::padded(vt.addend_size * (longest + 1)) : 0;
+  const size_t partial_bytes = static_cast<size_t>(psize) * lead;
+  ds.io.reset(kRegions * region_bytes + addend_bytes + rest_bytes +
+                  device_arena::padded(partial_bytes * chunks) +
                   device_arena::padded(static_cast<size_t>(out_stride) * num_sequences) + 4096,
               ds.stream);
   if (ds.copy_stream == nullptr) {
@@ -394,21 +429,22 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
   };
   struct region {
     u8* api = nullptr;
-    void* addends = nullptr;
     std::vector<u8*> columns;
   } regions[kRegions];
   for (auto& r : regions) {
-    if (upload_generators) {
-      r.api = ds.io.take<u8>(vt.api_generator_size * rows_max + 32);
-      r.addends = ds.io.take<u8>(vt.addend_size * (rows_max + 1));
-    }
-    for (const auto& c : cols) {
+    if (upload_generators) r.api = ds.io.take<u8>(vt.api_generator_size * rows_max + 32);
+    for (const auto& c : lead_cols) {
       r.columns.push_back(ds.io.take<u8>(static_cast<size_t>(std::min<u64>(c.n, rows_max)) * c.row_stride + 32));
     }
   }
+  u8* d_addends_all = upload_generators ? ds.io.take<u8>(vt.addend_size * (longest + 1)) : nullptr;
+  std::vector<u8*> d_rest;
+  for (const auto& c : rest_cols) {
+    d_rest.push_back(c.n == 0 ? nullptr : ds.io.take<u8>(static_cast<size_t>(c.n) * c.row_stride + 32));
+  }
   u8* d_partials = ds.io.take<u8>(partial_bytes * chunks);
   u8* d_out = ds.io.take<u8>(static_cast<size_t>(out_stride) * num_sequences);
-  // the io arena may have been reallocated on ds.stream: the copy stream starts behind it
+  // the io arena may have been reallocated on ds.stream: the copy streams start behind it
   hipEvent_t ready = new_event();
   BZ_HIP_CHECK(hipEventRecord(ready, ds.stream));
   BZ_HIP_CHECK(hipStreamWaitEvent(ds.copy_stream, ready, 0));
@@ -417,31 +453,52 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
   if (resident && ds.builtin.tables() != nullptr && longest <= ds.builtin.shape.stride - gens.offset) {
     tables = ds.builtin.shape;
   }
-  // hipMemcpyAsync from pageable memory occupies the calling host thread for the length of the copy
-  // (the runtime stages the data itself), and enqueueing a chunk's kernels costs ~0.1 ms of host
-  // time: done by one thread, every enqueue is a gap in the upload (measured: 8 chunks 4.99 ms
-  // against 4.86 unpipelined).  So the uploads run on a helper thread, back to back; the calling
-  // thread enqueues chunk k's work as soon as the helper has issued chunk k's copies.
-  std::vector<hipEvent_t> computed(chunks), copied(chunks);
+  // the columns after the lead in batches of whole columns, as enqueue_commitments cuts them
+  constexpr size_t kBatchBytes = size_t{48} << 20;
+  std::vector<std::pair<size_t, size_t>> batches;
+  for (size_t begin = 0; begin < rest_cols.size();) {
+    size_t end = begin, bytes = 0;
+    while (end < rest_cols.size() && (end == begin || bytes < kBatchBytes)) {
+      bytes += static_cast<size_t>(rest_cols[end].n) * rest_cols[end].row_stride;
+      ++end;
+    }
+    batches.emplace_back(begin, end);
+    begin = end;
+  }
+  std::vector<hipEvent_t> computed(chunks), copied(chunks), copied_batch(batches.size());
   for (u32 k = 0; k < chunks; ++k) {
     computed[k] = new_event();
     copied[k] = new_event();
   }
+  for (auto& e : copied_batch) e = new_event();
   struct chunk_range {
     u64 begin, end;
-    std::vector<host_column> columns; // device pointers once staged
+    std::vector<host_column> columns; // the lead columns' rows of the range (host pointers)
   };
   std::vector<chunk_range> ranges(chunks);
   for (u32 k = 0; k < chunks; ++k) {
     ranges[k].begin = static_cast<u64>(static_cast<unsigned __int128>(longest) * k / chunks);
     ranges[k].end = static_cast<u64>(static_cast<unsigned __int128>(longest) * (k + 1) / chunks);
-    ranges[k].columns = row_range_of(cols, ranges[k].begin, ranges[k].end);
+    ranges[k].columns = row_range_of(lead_cols, ranges[k].begin, ranges[k].end);
   }
   std::mutex mu;
   std::condition_variable cv;
-  u32 issued = 0;    // chunks whose copies (and `copied` event) are in the copy stream
-  u32 enqueued = 0;  // chunks whose `computed` event is in the compute stream
+  u32 issued = 0;         // chunks whose copies (and `copied` event) are in the copy stream
+  u32 issued_batches = 0; // the same for the batches of whole columns
+  u32 enqueued = 0;          // chunks whose `computed` event is in the compute stream
   const int device = ds.device;
+  auto publish = [&](u32& counter, u32 value) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      counter = value;
+    }
+    cv.notify_all();
+  };
+  // hipMemcpyAsync from pageable memory occupies the calling host thread for the length of the copy
+  // (the runtime stages the data itself), and enqueueing a chunk's kernels costs ~0.1 ms of host
+  // time: done by one thread, every enqueue is a gap in the upload (measured: 8 chunks 4.99 ms
+  // against 4.86 unpipelined).  So the uploads run on a helper thread, back to back; the calling
+  // thread enqueues chunk k's work as soon as the helper has issued chunk k's copies.
   std::thread uploader([&] {
     BZ_HIP_CHECK(hipSetDevice(device));
     for (u32 k = 0; k < chunks; ++k) {
@@ -449,13 +506,14 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
       if (k >= kRegions) {
         // the region is free once chunk k - kRegions has been computed: wait until that event has
         // been recorded by the other thread, then let the copy stream wait for it
-        std::unique_lock<std::mutex> lock(mu);
-        cv.wait(lock, [&] { return enqueued >= k - kRegions + 1; });
-        lock.unlock();
+        {
+          std::unique_lock<std::mutex> lock(mu);
+          cv.wait(lock, [&] { return enqueued >= k - kRegions + 1; });
+        }
         BZ_HIP_CHECK(hipStreamWaitEvent(ds.copy_stream, computed[k - kRegions], 0));
       }
       const chunk_range& cr = ranges[k];
-      if (upload_generators) {
+      if (upload_generators && cr.end > cr.begin) {
         BZ_HIP_CHECK(hipMemcpyAsync(r.api, static_cast<const u8*>(gens.host_generators) +
                                                vt.api_generator_size * cr.begin,
                                     vt.api_generator_size * (cr.end - cr.begin),
@@ -468,13 +526,20 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
                                     hipMemcpyHostToDevice, ds.copy_stream));
       }
       BZ_HIP_CHECK(hipEventRecord(copied[k], ds.copy_stream));
-      {
-        std::lock_guard<std::mutex> lock(mu);
-        issued = k + 1;
+      publish(issued, k + 1);
+    }
+    for (size_t b = 0; b < batches.size(); ++b) {
+      for (size_t c = batches[b].first; c < batches[b].second; ++c) {
+        if (rest_cols[c].n == 0) continue;
+        BZ_HIP_CHECK(hipMemcpyAsync(d_rest[c], rest_cols[c].data,
+                                    static_cast<size_t>(rest_cols[c].n) * rest_cols[c].row_stride,
+                                    hipMemcpyHostToDevice, ds.copy_stream));
       }
-      cv.notify_all();
+      BZ_HIP_CHECK(hipEventRecord(copied_batch[b], ds.copy_stream));
+      publish(issued_batches, static_cast<u32>(b + 1));
     }
   });
+  const bool several_calls = chunks > 1 || !batches.empty();
   for (u32 k = 0; k < chunks; ++k) {
     region& r = regions[k % kRegions];
     {
@@ -486,11 +551,14 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
     for (size_t c = 0; c < mine.size(); ++c) mine[c].data = mine[c].n == 0 ? nullptr : r.columns[c];
     const u64 rows = ranges[k].end - ranges[k].begin;
     u8* out_k = d_partials + partial_bytes * k;
-    if (chunks > 1) msm_context_defer_next_tail(ds.ctx);
+    if (several_calls) msm_context_defer_next_tail(ds.ctx);
     if (upload_generators) {
-      vt.prepare_addends(r.addends, r.api, rows, ds.stream);
-      g_kernel_launches += 1;
-      vt.msm(*ds.ctx, out_k, psize, true, mine, r.addends, nullptr, ds.stream);
+      u8* addends_k = d_addends_all + vt.addend_size * ranges[k].begin;
+      if (rows > 0) {
+        vt.prepare_addends(addends_k, r.api, rows, ds.stream);
+        g_kernel_launches += 1;
+      }
+      vt.msm(*ds.ctx, out_k, psize, true, mine, addends_k, nullptr, ds.stream);
     } else {
       // a range of a resident set: the same rows of every window-table slice
       const void* d_addends =
@@ -499,18 +567,36 @@ u8* enqueue_commitments_row_pipeline(api_state& st, device_state& ds, const curv
                       tables.windows != 0 ? &tables : nullptr);
     }
     BZ_HIP_CHECK(hipEventRecord(computed[k], ds.stream));
+    publish(enqueued, k + 1);
+  }
+  // the other columns, whole: every addend is in place behind the last chunk's conversion
+  for (size_t b = 0; b < batches.size(); ++b) {
     {
-      std::lock_guard<std::mutex> lock(mu);
-      enqueued = k + 1;
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return issued_batches > b; });
     }
-    cv.notify_all();
+    BZ_HIP_CHECK(hipStreamWaitEvent(ds.stream, copied_batch[b], 0));
+    std::vector<host_column> batch(rest_cols.begin() + batches[b].first,
+                                   rest_cols.begin() + batches[b].second);
+    for (size_t c = 0; c < batch.size(); ++c) {
+      batch[c].data = batch[c].n == 0 ? nullptr : d_rest[batches[b].first + c];
+    }
+    u8* out_b = d_out + (lead + batches[b].first) * static_cast<size_t>(out_stride);
+    msm_context_defer_next_tail(ds.ctx);
+    if (upload_generators) {
+      vt.msm(*ds.ctx, out_b, out_stride, projective_out, batch, d_addends_all, nullptr, ds.stream);
+    } else {
+      vt.msm_resident(*ds.ctx, out_b, out_stride, projective_out, batch,
+                      ds.builtin.rows_from(gens.offset, vt.resident_addend_size), ds.stream,
+                      tables.windows != 0 ? &tables : nullptr);
+    }
   }
   uploader.join();
   msm_context_join_tail(ds.ctx, ds.stream);
   if (projective_out) {
-    vt.fold_device(d_out, d_partials, chunks, num_sequences, ds.stream);
+    vt.fold_device(d_out, d_partials, chunks, lead, ds.stream);
   } else {
-    vt.fold_encode_device(d_out, d_partials, chunks, num_sequences, ds.stream);
+    vt.fold_encode_device(d_out, d_partials, chunks, lead, ds.stream);
   }
   g_kernel_launches += 1;
   (void)st;
@@ -605,13 +691,13 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
                                 offset_generators <= st.host_generators.size() &&
                                 cc.longest <= st.host_generators.size() - offset_generators &&
                                 ds.builtin.d_addends != nullptr;
-    u32 chunks = 1;
+    row_pipeline_shape shape;
     if (source == generator_source::host_api || cached_builtin) {
-      chunks = choose_row_chunks(vt, cc.cols, cc.longest, source == generator_source::host_api);
+      shape = choose_row_chunks(vt, cc.cols, cc.longest, source == generator_source::host_api);
     }
-    u8* d_out = chunks > 1
+    u8* d_out = shape.chunks > 1
                     ? enqueue_commitments_row_pipeline(st, ds, vt, cc.cols, cc.longest, all_gens,
-                                                       out_stride, projective_out, chunks, events)
+                                                       out_stride, projective_out, shape, events)
                     : enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
                                           projective_out, events);
     BZ_HIP_CHECK(hipMemcpyAsync(out, d_out, static_cast<size_t>(out_stride) * num_sequences,

@@ -4,7 +4,8 @@
 // benchmark/multi_commitment/benchmark.m.cc:204-236, cloned in tools/multi_commitment; this driver adds
 // warm-up calls, the built-in generators and a result check).
 //
-//   hostapi_bench [--log2n 20] [--samples 10] [--warmup 2]
+//   hostapi_bench [--log2n 20] [--samples 10] [--warmup 2] [--only COLUMNS caller|builtin]
+//   (--only: that one case, for a rocprofv3 timeline of it: tools/prof/hostapi_timeline.py)
 //
 // For 1 and 10 columns of 2^log2n 32-byte scalars (std::mt19937{0} bytes, column-major, top nibble
 // masked: BASELINE configs[1]'s scalars) it times
@@ -32,13 +33,18 @@ static double now_ms() {
 }
 
 int main(int argc, char** argv) {
-  unsigned log2n = 20, samples = 10, warmup = 2;
+  unsigned log2n = 20, samples = 10, warmup = 2, only_columns = 0;
+  int only_builtin = -1;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&] { return static_cast<unsigned>(std::atoi(argv[++i])); };
     if (a == "--log2n") log2n = next();
     else if (a == "--samples") samples = next();
     else if (a == "--warmup") warmup = next();
+    else if (a == "--only") {
+      only_columns = next();
+      only_builtin = std::string(argv[++i]) == "builtin" ? 1 : 0;
+    }
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());
       return 2;
@@ -59,12 +65,14 @@ int main(int argc, char** argv) {
   std::printf("{\"log2n\": %u, \"samples\": %u, \"warmup\": %u, \"cases\": [", log2n, samples, warmup);
   bool first = true, all_agree = true;
   for (unsigned columns : {1u, max_columns}) {
+    if (only_columns != 0 && columns != only_columns) continue;
     std::vector<sxt_sequence_descriptor> desc(columns);
     for (unsigned c = 0; c < columns; ++c) {
       desc[c] = sxt_sequence_descriptor{32, n, data.data() + static_cast<size_t>(c) * n * 32, 0};
     }
     std::vector<sxt_ristretto255_compressed> with_caller(columns), with_builtin(columns);
     for (int builtin = 0; builtin < 2; ++builtin) {
+      if (only_builtin >= 0 && builtin != only_builtin) continue;
       auto call = [&] {
         if (builtin) {
           sxt_curve25519_compute_pedersen_commitments(with_builtin.data(), columns, desc.data(), 0);
@@ -91,7 +99,9 @@ int main(int argc, char** argv) {
                                                   (builtin ? 0 : n * sizeof(sxt_ristretto255))));
       first = false;
     }
-    all_agree = all_agree && std::memcmp(with_caller.data(), with_builtin.data(), 32 * columns) == 0;
+    if (only_builtin < 0) {
+      all_agree = all_agree && std::memcmp(with_caller.data(), with_builtin.data(), 32 * columns) == 0;
+    }
   }
   std::printf("], \"caller_and_builtin_generators_agree\": %s}\n", all_agree ? "true" : "false");
   return all_agree ? 0 : 1;
