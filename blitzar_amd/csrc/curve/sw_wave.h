@@ -113,7 +113,10 @@ template <class G> struct wave {
     c.live = c.j < NW ? ~0u : 0u;
     c.top = c.j == NW - 1 ? ~0u : 0u;
     u32 b = 0;
-    unroll<NW>([&](auto k) { b = c.j == static_cast<u32>(decltype(k)::value) ? P::wave_bias(decltype(k)::value) : b; });
+    unroll<NW>([&](auto k) {
+      constexpr int i = decltype(k)::value;
+      b = c.j == static_cast<u32>(i) ? P::wave_bias(i) : b;
+    });
     c.bias = b;
     c.lds = lds;
     return c;
@@ -240,7 +243,8 @@ template <class G> struct wave {
     const uint4 a = exchange(c, st); // X1 Y1 Z1
     const uint4 b = exchange(c, q);  // X2 Y2 Z2
     // round 1: X1 X2 | Y1 Y2 | Z1 Z2 | (X1 + Y1)(X2 + Y2)
-    const uint4 r1 = exchange(c, fmul(c, by_row(c, a.x, a.y, a.z, a.x + a.y), by_row(c, b.x, b.y, b.z, b.x + b.y)));
+    const uint4 r1 = exchange(c, fmul(c, by_row(c, a.x, a.y, a.z, a.x + a.y),
+                                      by_row(c, b.x, b.y, b.z, b.x + b.y)));
     const u32 t0 = r1.x, t1 = r1.y, t2 = r1.z;
     const u32 ub = scale<G::b3_abs>(t2);
     const u32 t00 = 3 * t0;
@@ -254,7 +258,8 @@ template <class G> struct wave {
       t1m = t1 + ub;
     }
     // round 2: (Y1 + Z1)(Y2 + Z2) | (X1 + Z1)(X2 + Z2) | t1m z3 | 3 t0 t3
-    const uint4 r2 = exchange(c, fmul(c, by_row(c, a.y + a.z, a.x + a.z, t1m, t00), by_row(c, b.y + b.z, b.x + b.z, z3, t3)));
+    const uint4 r2 = exchange(c, fmul(c, by_row(c, a.y + a.z, a.x + a.z, t1m, t00),
+                                      by_row(c, b.y + b.z, b.x + b.z, z3, t3)));
     const u32 t4 = carry1(sub(c, r2.x, t1 + t2));
     const u32 t5 = carry1(sub(c, r2.y, t0 + t2));
     const u32 y3 = scale<G::b3_abs>(t5);
@@ -297,7 +302,10 @@ template <class G> struct wave {
   // coordinate below 1.001 p with a zero top lane, the carry sweep of F::norm makes the limbs exact
   __device__ static __forceinline__ point store_point(const ctx& c, u32 st) {
     u32 one = 0;
-    unroll<NW>([&](auto k) { one = c.j == static_cast<u32>(decltype(k)::value) ? P::wave_one(decltype(k)::value) : one; });
+    unroll<NW>([&](auto k) {
+      constexpr int i = decltype(k)::value;
+      one = c.j == static_cast<u32>(i) ? P::wave_one(i) : one;
+    });
     const u32 r = fmul(c, st, one);
     c.lds->io[c.lane] = r;
     wave_lds_sync();
