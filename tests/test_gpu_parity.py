@@ -730,6 +730,15 @@ def test_blocking_call_as_a_row_pipeline(gpu_backend, oracle, curve_id, chunks):
         got = api.compute_pedersen_commitments(curve_id, cols, generators=g_api)
         assert lib.bzamd_kernel_launch_count() - before >= 6 * chunks  # every chunk ran the engine
         assert np.array_equal(got, want)
+        # with caller generators the first four columns are cut into the chunks and the others follow
+        # whole on the addends the chunks left: the longest column last (the lead columns end before
+        # the generators do: their later chunks are empty), and six columns (two whole ones)
+        back = [cols[2], cols[3], cols[1], cols[4], cols[0]]
+        assert np.array_equal(api.compute_pedersen_commitments(curve_id, back, generators=g_api),
+                              want[[2, 3, 1, 4, 0]])
+        six = cols + [(rng.integers(0, 256, (n - 7, 32), dtype=np.uint8), False)]
+        assert np.array_equal(api.compute_pedersen_commitments(curve_id, six, generators=g_api),
+                              oracle.commit(curve_id, six, gens))
         if curve_id == 0:
             # the session's backend caches 100 built-in generators: rows 0..99 resident, the rest of
             # a longer column derived on the fly (that shape is not pipelined; it must still agree)
