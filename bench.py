@@ -707,10 +707,15 @@ def main():
     coll = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        # a rendezvous or a collective that never completes must end the run with an error, not hold
+        # the node for the backend's default of ten minutes and more
+        limit = datetime.timedelta(seconds=240)
         if args.dry_run_one_gpu:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=limit)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+            # nccl == RCCL on ROCm
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=limit)
         coll = Collectives(dist, args.dry_run_one_gpu)
     # one process per GPU: the library's own multi-device sharding stays off, this process drives
     # the device torch selected
