@@ -841,3 +841,53 @@ def test_blocking_call_of_two_chunks_bn254(gpu_backend, oracle):
     want = oracle.commit(2, cols, gens)
     got = api.compute_pedersen_commitments(2, cols, generators=util.api_generators(2, gens))
     assert np.array_equal(got, want)
+
+
+_FORCED_KNOB_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from blitzar_amd import api
+data = np.load(sys.argv[2])
+assert api.init(api.SXT_GPU_BACKEND, 0) == 0
+lib = api.load()
+lib.bzamd_set_window_bits(16)  # 32768 buckets per window: 16 k_reduce blocks per task
+out = {}
+for cid in (0, 1, 2, 3):
+    cols = [(data[f"s{cid}_{k}"], False) for k in range(2)]
+    out[f"c{cid}"] = api.compute_pedersen_commitments(cid, cols, generators=data[f"g{cid}"])
+np.savez(sys.argv[3], **out)
+"""
+
+
+@pytest.mark.parametrize("knobs", [{"BLITZAR_AMD_COMPACT_REDUCE": "1"}, {"BLITZAR_AMD_COMPACT_REDUCE": "0"}])
+def test_bucket_reduction_variants_forced(gpu_backend, oracle, tmp_path, knobs):
+    """k_reduce_compact (what the engine picks on its own only on boxes with slow instruction fetch)
+    and the inlined k_reduce, each forced in a process of its own, on columns whose windows span 16
+    reduce blocks (the suffix scan's block offset -- one multiple per workgroup on the lane-spread
+    form -- is only reached from the second block on): all four curves against the reference"""
+    import subprocess
+    import sys
+    n = 1 << 13
+    rng = np.random.default_rng(77)
+    arrays, want = {}, {}
+    for cid in (0, 1, 2, 3):
+        gens = util.generators_for(cid, n)
+        arrays[f"g{cid}"] = util.api_generators(cid, gens)
+        cols = []
+        for k in range(2):
+            s = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            s[:, 31] &= 0x0f
+            arrays[f"s{cid}_{k}"] = s
+            cols.append((s, False))
+        want[cid] = oracle.commit(cid, cols, gens)
+    src, dst = tmp_path / "in.npz", tmp_path / "out.npz"
+    np.savez(src, **arrays)
+    env = dict(os.environ, **knobs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FORCED_KNOB_SCRIPT, root, str(src), str(dst)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(dst)
+    for cid in (0, 1, 2, 3):
+        assert np.array_equal(got[f"c{cid}"], want[cid]), f"curve {cid} under {knobs}"
