@@ -381,7 +381,7 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
 
     dt, stages = timed_calls(lib, step, steps, 1, stream)
     got = res.cpu().numpy()
-    lone = lone_calls(step)
+    lone = lone_calls(step, lib=lib)
     sums = wl.weighted_byte_sums(scalars)
     bad = []
     for k in range(outputs):
@@ -398,6 +398,7 @@ def config5(lib, oracle, steps, dev, stream, outputs=1024, log2n=18):
                        "8/32/256-bit fields", "rows": n, "outputs": outputs,
              "bits_per_row": int(bit_table.sum()), "ms_per_call": dt * 1e3,
              "lone_call_ms": round(lone["min"], 4), "lone_call_ms_mean": round(lone["mean"], 4),
+             "lone_call_stage_ms": lone["stages"],
              "row_output_ops_per_s": ops / dt, "outputs_per_s": outputs / dt,
              "handle_creation_s": handle_s,
              "data": "mt19937{0} bytes (tools/mt19937: the one serial stream produced on all host "
