@@ -27,6 +27,9 @@ STAGES = ["prepare_addends", "recode", "bucket_sort", "accumulate", "reduce", "c
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=14)
+    ap.add_argument("--full-width-only", action="store_true",
+                    help="only the 32-byte case (for a rocprofv3 --kernel-trace --stats run: every "
+                         "kernel of the trace then belongs to a lone full-width call)")
     args = ap.parse_args()
     lib = api.load()
     api.init(api.SXT_GPU_BACKEND)
@@ -49,7 +52,7 @@ def main():
             gens = torch.from_numpy(host).to(dev)
         res = torch.zeros((1, out_size), dtype=torch.uint8, device=dev)
         row = {}
-        for nbytes in (2, 4, 8, 16, 24, 32):
+        for nbytes in ((32,) if args.full_width_only else (2, 4, 8, 16, 24, 32)):
             s = np.zeros((n, 32), dtype=np.uint8)
             s[:, :nbytes] = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
             if nbytes == 32:
@@ -76,6 +79,9 @@ def main():
             row[nbytes] = {"combine_ms": round(best[5], 4), "reduce_ms": round(best[4], 4)}
         out[name] = row
         c = {b: row[b]["combine_ms"] for b in row}
+        if args.full_width_only:
+            print(f"{name:11s} lone call, 2^{args.log2n} rows: reduce {row[32]['reduce_ms']} ms, combine {c[32]} ms")
+            continue
         per_window = (c[32] - c[8]) / 12.0
         print(f"{name:11s} combine ms by scalar bytes {c}  -> per window {per_window * 1e3:.1f} us, "
               f"rest {c[32] - 15 * per_window:.4f} ms")
