@@ -36,6 +36,8 @@ def main():
     dev = torch.device("cuda:0")
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(5)
+    lib.bzamd_slow_instruction_fetch.restype = ctypes.c_int
+    print("slow_instruction_fetch:", lib.bzamd_slow_instruction_fetch())
     n = 1 << args.log2n
     out = {}
     for cid, name in ((0, "curve25519"), (1, "bls12-381"), (2, "bn254"), (3, "grumpkin")):

@@ -116,6 +116,20 @@ template <int Blocks2048> __global__ void k_icache(uint64_t* out, uint32_t seed,
   }
   out[threadIdx.x] = a;
 }
+// The same chain as a LOOP whose body is 16 .. 1024 instructions (all of it in the instruction cache):
+// what a taken branch costs one wavefront.  (k_horner's chains are such loops: 150 .. 760 instructions
+// per doubling / addition.)
+template <int Body16> __global__ void k_loop(uint64_t* out, uint32_t seed, int rounds) {
+  uint32_t a = seed + threadIdx.x;
+#pragma unroll 1
+  for (int r = 0; r < rounds; ++r) {
+    R16(IADD(a))
+    if constexpr (Body16 >= 4) { R16(IADD(a)) R16(IADD(a)) R16(IADD(a)) }
+    if constexpr (Body16 >= 16) { R16(IADD(a)) R16(IADD(a)) R16(IADD(a)) R16(IADD(a)) R4(R16(IADD(a))) R4(R16(IADD(a))) }
+    if constexpr (Body16 >= 64) { R16(R16(IADD(a))) R16(R16(IADD(a))) R16(R16(IADD(a))) }
+  }
+  out[threadIdx.x] = a;
+}
 // dependent global loads (pointer chase) of one lane over a ring of `count` 128-byte lines
 __global__ void k_chase(uint64_t* out, const uint32_t* __restrict__ ring, int steps) {
   uint32_t at = 0;
@@ -193,6 +207,28 @@ int main() {
         {"512 KiB", k_icache<32>, 32 * 2048},
     };
     for (const auto& c : ic) {
+      const int rounds = (1 << 19) / c.instrs;
+      hipLaunchKernelGGL(c.fn, dim3(1), dim3(64), 0, s1, d_out, 1u, 2);
+      CHECK(hipStreamSynchronize(s1));
+      CHECK(hipEventRecord(e0, s1));
+      hipLaunchKernelGGL(c.fn, dim3(1), dim3(64), 0, s1, d_out, 2u, rounds);
+      CHECK(hipEventRecord(e1, s1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      std::printf("%-44s %12.2f\n", c.name, ms * 1e6 / (static_cast<double>(rounds) * c.instrs));
+    }
+  }
+  // a loop of the same instructions against the length of its body
+  std::printf("\n%-44s %12s\n", "loop walked by one wavefront, body of", "ns / instr");
+  {
+    struct { const char* name; void (*fn)(uint64_t*, uint32_t, int); int instrs; } lp[] = {
+        {"16 instructions", k_loop<1>, 16},
+        {"64", k_loop<4>, 64},
+        {"256", k_loop<16>, 256},
+        {"1024", k_loop<64>, 1024},
+    };
+    for (const auto& c : lp) {
       const int rounds = (1 << 19) / c.instrs;
       hipLaunchKernelGGL(c.fn, dim3(1), dim3(64), 0, s1, d_out, 1u, 2);
       CHECK(hipStreamSynchronize(s1));
