@@ -68,12 +68,6 @@ def parse_args():
                     help="profiling runs: keep the oracle for the configs legs but skip the 16 s "
                          "reference-CPU run on the headline column (no `verified`, no cpu_baseline)")
     ap.add_argument("--config-steps", type=int, default=3)
-    ap.add_argument("--arrangement", type=int, default=None, choices=[0, 1, 2, 3],
-                    help="run the throughput mode in this arrangement (bzamd_pipeline_arrangement) "
-                         "instead of the library's default (0)")
-    ap.add_argument("--search-arrangements", action="store_true",
-                    help="measure the arrangements 1..3 (three stream layouts each), untimed, and keep "
-                         "the first one 3 %% faster than the default; one rank only")
     ap.add_argument("--no-aux", action="store_true",
                     help="profiling runs: skip the device_state legs (3000 extra calls) and the "
                          "host_api child processes")
@@ -838,47 +832,7 @@ def main():
             legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 30 + calls
             return begin.elapsed_time(end) / calls
 
-        # Where the front of a pipelined call runs (include/blitzar_amd.h, bzamd_pipeline_arrangement):
-        # on the caller's stream (0, the library's default and what this line measures) or on an
-        # internal stream beside the previous call's accumulation (1..3).  Which is fastest depends on
-        # how the process's streams share the device's hardware queues: in a small torch script the
-        # split arrangements gain 3-4 %, in a process with one stream they lose 2-25 %
-        # (profiles/round4_front_arrangements.txt), and in THIS process a walk through three stream
-        # layouts per arrangement found 0.931-0.943 once and 1.00-1.08 otherwise against 0.954-0.956
-        # for the default (profiles/round4_arrangement_search.json): nothing to keep.  The walk stays
-        # behind --search-arrangements (one rank only), --arrangement pins one.
-        baseline = sustained()  # arrangement 0
-        tried = [{"arrangement": 0, "ms": round(baseline, 4)}]
-        best = 0
-        if args.arrangement is not None:
-            best = args.arrangement
-            lib.bzamd_pipeline_arrangement(best)
-        elif args.search_arrangements and world == 1:
-            # every call of bzamd_pipeline_arrangement makes a NEW pair of internal streams, which the
-            # runtime binds to the next hardware queues in its rotation: a few attempts per
-            # arrangement walk through the layouts this process can get.  The first layout that is
-            # 3 % faster than the default is kept as it stands (its streams are not touched again);
-            # if none is, the default stays.
-            baseline = min(baseline, sustained())
-            tried[0]["ms"] = round(baseline, 4)
-            for arrangement, attempt in [(a, t) for t in range(3) for a in (2, 1, 3)]:
-                lib.bzamd_pipeline_arrangement(arrangement)
-                ms = sustained()
-                tried.append({"arrangement": arrangement, "attempt": attempt, "ms": round(ms, 4)})
-                if ms < 0.97 * baseline:
-                    best = arrangement
-                    break
-            if best == 0:
-                lib.bzamd_pipeline_arrangement(0)
-        legs["arrangement"] = {"chosen": best, "tried": tried,
-                               "meaning": "0: the front of a call on the caller's stream (the library's "
-                                          "default); 1-3: on an internal stream beside the previous "
-                                          "call's accumulation (1: high-priority front stream + a "
-                                          "dedicated accumulation queue, 2: two plain streams, 3: "
-                                          "high-priority front stream + a plain accumulation stream); "
-                                          "`tried`: sustained ms per step of every layout measured, "
-                                          "untimed (more than the default only under "
-                                          "--search-arrangements / --arrangement)"}
+        sustained()  # (the first sequence after the workspace was sized)
         legs["sustained_ms"] = sustained()
         legs["sustained_calls"] = calls
         legs["untimed_calls_before_clock"] = legs.get("untimed_calls_before_clock", 0) + 2
@@ -917,8 +871,6 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed_stages, calls = clock.collect(args.steps)
-    if legs["arrangement"]["chosen"] != 0:
-        lib.bzamd_pipeline_arrangement(0)  # the configs legs below run in the default arrangement
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
@@ -1010,7 +962,6 @@ def main():
             "single_call_ms": single_call_ms,
             "sustained_ms_per_step": legs["sustained_ms"],
             "sustained_steps": legs["sustained_calls"],
-            "pipeline_arrangement": legs["arrangement"],
             "mode": "throughput mode of the library (bzamd_pipeline_next / bzamd_pipeline_flush): the "
                     "last stage of step k (one workgroup per column) runs beside the front of step "
                     "k + 1; all K commitments are complete, and the last one verified, inside the "

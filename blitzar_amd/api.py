@@ -100,8 +100,6 @@ def load():
     lib.bzamd_set_segments.restype = None
     lib.bzamd_stage_timing_begin.argtypes = [u64]
     lib.bzamd_stage_timing_begin.restype = None
-    lib.bzamd_pipeline_arrangement.argtypes = [u32]
-    lib.bzamd_pipeline_arrangement.restype = None
     lib.bzamd_pipeline_next.argtypes = []
     lib.bzamd_pipeline_next.restype = None
     lib.bzamd_pipeline_flush.argtypes = [ctypes.c_void_p]

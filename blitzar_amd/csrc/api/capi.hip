@@ -1574,12 +1574,6 @@ void bzamd_pipeline_next(void) {
   t_pipeline_next = true;
 }
 
-void bzamd_pipeline_arrangement(uint32_t arrangement) {
-  api_state& st = state();
-  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");
-  msm_context_set_arrangement(st.context_for_current_device(), arrangement);
-}
-
 void bzamd_pipeline_flush(void* stream) {
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "device entry points need the GPU backend");

@@ -101,9 +101,6 @@ msm_context* msm_context_new() {
     msm_context_set_segments(ctx, ctx->tuning.force_segment_log2,
                              static_cast<u32>(std::strtoul(v, nullptr, 10)));
   }
-  if (const char* v = std::getenv("BLITZAR_AMD_DEFER_COLUMNS")) {
-    ctx->tuning.defer_max_columns = static_cast<size_t>(std::strtoul(v, nullptr, 10));
-  }
   if (const char* v = std::getenv("BLITZAR_AMD_SEGMENT_LOG2")) {
     msm_context_set_segments(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)),
                              ctx->tuning.force_reduce_segment_log2);
@@ -116,40 +113,12 @@ msm_context* msm_context_new() {
     if (const char* v = std::getenv(name)) out = !(v[0] == '0' && v[1] == 0);
   };
   flag("BLITZAR_AMD_OVERLAP_TAILS", ctx->overlap_tails);
-  flag("BLITZAR_AMD_OVERLAP_FRONT", ctx->overlap_front);
-  flag("BLITZAR_AMD_FRONT_PRIORITY", ctx->front_high_priority);
-  flag("BLITZAR_AMD_DEDICATED_QUEUES", ctx->dedicated_queues);
-  flag("BLITZAR_AMD_FAST_RECODE", ctx->fast_recode);
-  flag("BLITZAR_AMD_TAIL_LOW_PRIORITY", ctx->tail_low_priority);
-  flag("BLITZAR_AMD_FUSE_OFFSETS", ctx->fuse_offsets);
-  if (const char* v = std::getenv("BLITZAR_AMD_SORT_STREAM_FACTOR")) {
-    const unsigned long f = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(f >= 1 && f <= 16, "BLITZAR_AMD_SORT_STREAM_FACTOR must be in [1, 16]");
-    ctx->sort_stream_factor = static_cast<u32>(f);
-  }
-  if (const char* v = std::getenv("BLITZAR_AMD_FUSE_BIG")) {
-    const unsigned long m = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(m <= 2, "BLITZAR_AMD_FUSE_BIG must be 0, 1 or 2");
-    ctx->fuse_big = static_cast<u32>(m);
-  }
-  flag("BLITZAR_AMD_RANK_ONCE", ctx->rank_once);
   if (const char* v = std::getenv("BLITZAR_AMD_COMPACT_REDUCE")) {
     const unsigned long m = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(m <= 2, "BLITZAR_AMD_COMPACT_REDUCE must be 0 (never), 1 (always) or 2 (probe)");
     ctx->compact_reduce = static_cast<u32>(m);
   }
   if (ctx->compact_reduce == 2) ctx->slow_instruction_fetch = probe_slow_instruction_fetch();
-  if (const char* v = std::getenv("BLITZAR_AMD_TAIL_STREAMS")) {
-    const unsigned long streams = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(streams == 1 || streams == 2, "BLITZAR_AMD_TAIL_STREAMS must be 1 or 2");
-    ctx->two_tail_streams = streams == 2;
-  }
-  if (const char* v = std::getenv("BLITZAR_AMD_FRONT_CUS")) {
-    const unsigned long cus = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(cus <= 128, "BLITZAR_AMD_FRONT_CUS must be in [0, 128]");
-    ctx->front_cus = static_cast<u32>(cus);
-  }
-
   return ctx;
 }
 void msm_context_free(msm_context* ctx) { delete ctx; }
@@ -181,25 +150,6 @@ void msm_context_set_window_bits(msm_context* ctx, u32 window_bits) {
                     "window width must be 2..16 (0 = automatic)");
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->tuning.force_window_bits = window_bits;
-}
-void msm_context_set_arrangement(msm_context* ctx, u32 arrangement) {
-  BZ_RELEASE_ASSERT(arrangement <= 3, "throughput-mode arrangement must be 0..3");
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  BZ_RELEASE_ASSERT(!ctx->any_pending(),
-                    "flush the throughput mode (bzamd_pipeline_flush) before changing its arrangement");
-  // the front / accumulation streams are made for an arrangement: drop the old pair (idle: nothing is
-  // pending), the next pipelined call creates what the new arrangement needs
-  for (hipStream_t* s : {&ctx->front, &ctx->acc}) {
-    if (*s != nullptr) {
-      BZ_HIP_CHECK(hipStreamSynchronize(*s));
-      BZ_HIP_CHECK(hipStreamDestroy(*s));
-      *s = nullptr;
-    }
-  }
-  ctx->overlap_front = arrangement != 0;
-  ctx->front_high_priority = arrangement == 1 || arrangement == 3;
-  ctx->dedicated_queues = arrangement == 1;
-  ctx->front_cus = 0;
 }
 void msm_context_defer_next_tail(msm_context* ctx) {
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -95,11 +95,6 @@ void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_ta
 void msm_context_set_window_bits(msm_context* ctx, u32 window_bits);
 // throughput mode (bzamd_msm_device_pipelined): the next MSM enqueued on this context leaves its last
 // stages running on the context's own streams; `join_tail` makes `stream` wait for everything pending
-// throughput mode, where the front (conversion, recoding, sort) of call k + 1 runs: 0 on the caller's
-// stream behind the accumulation of call k (default); 1..3 on an internal stream beside it --
-// 1: high-priority front stream, accumulation stream with a hardware queue of its own; 2: two plain
-// streams; 3: high-priority front stream, plain accumulation stream.  Nothing may be pending.
-void msm_context_set_arrangement(msm_context* ctx, u32 arrangement);
 void msm_context_defer_next_tail(msm_context* ctx);
 void msm_context_join_tail(msm_context* ctx, hipStream_t stream);
 // sorted entries per k_accumulate lane = 2^a (3..10), buckets per k_reduce lane = 2^r (1..8);

@@ -141,40 +141,25 @@ struct msm_context {
   // more than once, indexed by the batch's sequence number; completion marks (rings of 4 events)
   // order a stage behind the stage of an earlier batch whose buffers it reuses.
   //
-  // The same machinery can put the front and the accumulation on streams of their own as well
-  // (`overlap_front`, BLITZAR_AMD_OVERLAP_FRONT=1: front of batch k + 1 beside accumulation k; then
-  // everything the front writes exists twice and the bucket ends three times).  Measured on MI355X
-  // (round 3, profiles/round3_ab_front_*.log, round3_timeline_*.txt) and OFF by default:
-  //   * two big grids of one priority level do not run concurrently at all: the second kernel's
-  //     workgroups are dispatched when the first grid has been handed out completely (1.03 ms per
-  //     step against 1.00: only the extra events show);
-  //   * disjoint CU masks (`front_cus` CUs for the front, spread over the XCDs: KFD deals mask bit i
-  //     to XCC i mod 8) do run concurrently, but the front is not HBM-bound -- its kernels need
-  //     their share of the CUs' LDS-atomic and issue rate: on 32 CUs it takes 1.06 ms instead of
-  //     0.26 and becomes the bottleneck (1.13 ms per step; 64 CUs: 1.07);
-  //   * a high-priority queue for the front (`front_high_priority`) does interleave on shared CUs
-  //     (0.94 ms per step in a process of its own) but the accumulation slows by what the front
-  //     takes (0.65 -> 0.88 ms), and under PyTorch's 32-stream pool it gains nothing (1.09 against
-  //     1.08): not worth a mode that depends on how a process's queues are laid out.
-  //   * The caller's stream only carries waits in that mode: at entry the front stream waits for it
-  //     (the operands are ready), at the end of the call it waits for the batch's front (the
-  //     operands have been consumed).
-  // Either way a pipelined result is complete on the caller's stream once two further calls have
+  // (Front and accumulation on streams of their own as well -- plain streams, CU masks, queue
+  // priorities -- were built and measured in rounds 3 and 4 and removed: the front is not HBM-bound,
+  // there is nothing complementary to overlap, and what the arrangement gains or loses depends on how
+  // a process's streams share the hardware queues.  DESIGN.md history table; logs
+  // profiles/round3_ab_front_*.log, profiles/round4_front_arrangements.txt.)
+  // A pipelined result is complete on the caller's stream once two further calls have
   // been enqueued, or after bzamd_pipeline_flush.  Only while consecutive batches carve the arena
   // identically (same shapes, curve, mode: `pipe_layout`); any other call first joins everything
   // pending, and so does a re-allocation of the arena, a call outside the mode and a flush.
   // BLITZAR_AMD_OVERLAP_TAILS=0 switches the mode off altogether.  A lone call never forks (every
   // fork / join pair costs ~25 us of stream bubbles).
-  hipStream_t front = nullptr, acc = nullptr, tail = nullptr, tail2 = nullptr;
-  stage_mark entry;
-  stage_mark front_done[4], acc_done[4], reduce_done[4], horner_done[4];
+  hipStream_t tail = nullptr, tail2 = nullptr; // k_reduce / k_horner of a pipelined batch
+  stage_mark acc_done[4], reduce_done[4], horner_done[4];
   u64 seq = 0;            // pipelined batches enqueued so far on this context
   u64 joined = 0;         // the caller's stream `joined_on` has waited for every batch below this
   hipStream_t joined_on = nullptr;
   u64 pipe_layout = 0;        // layout tag of the pending batches
   bool defer_tail = false;    // the next call runs in throughput mode (msm_context_defer_next_tail)
   bool overlap_tails = true;  // BLITZAR_AMD_OVERLAP_TAILS=0: never fork
-  bool overlap_front = false; // BLITZAR_AMD_OVERLAP_FRONT=1: front + accumulation on streams of their own
   // The tail streams are non-blocking streams of the LOWEST priority.  Non-blocking: callers on the
   // NULL stream must not meet a blocking stream (every NULL-stream launch takes a dependency on
   // every blocking stream of the process, even an idle one: 1.00 -> 1.19 ms per call).  Lowest
@@ -186,26 +171,7 @@ struct msm_context {
   // calls' time to finish: whatever the caller's stream has ready goes first (a sequence of
   // config-2 calls 1.009 -> 0.988 ms per call against tails on CU-masked queues of their own, the
   // round's first answer to the multiplexing; profiles/round3_ab_tail_priority.log).
-  bool tail_low_priority = true; // BLITZAR_AMD_TAIL_LOW_PRIORITY=0: normal priority
-  bool two_tail_streams = true; // BLITZAR_AMD_TAIL_STREAMS=1: k_reduce and k_horner share one
-  u32 front_cus = 0;          // BLITZAR_AMD_FRONT_CUS: CUs reserved for the front stream (0: no masks)
-  bool front_high_priority = true; // BLITZAR_AMD_FRONT_PRIORITY=0: the front's queue at normal priority
-  // The front / accumulation streams of the overlap_front arrangement: a stream created with a CU
-  // mask -- here the mask of ALL CUs -- always gets a hardware queue of its own (see above).  Such
-  // streams are blocking streams, hence never for a caller on the NULL stream.
-  bool dedicated_queues = true; // BLITZAR_AMD_DEDICATED_QUEUES=0: plain non-blocking streams
-  bool fast_recode = true;      // BLITZAR_AMD_FAST_RECODE=0: the generic recode kernel for every shape
-  // the front of a call in fewer launches / LDS atomics (round 4; "=0": the separate kernels of
-  // round 3, kept for A/B runs):
-  bool fuse_offsets = true; // BLITZAR_AMD_FUSE_OFFSETS: pass 1b inside k_group_hist (last workgroup per task)
-  // BLITZAR_AMD_FUSE_BIG: the oversized-group path inside k_group_sort's launch -- 0: two launches
-  // of its own, 1: its histogram phase, 2: both phases (a barrier among its workers in between)
-  u32 fuse_big = 2;
-  bool rank_once = true;    // BLITZAR_AMD_RANK_ONCE: one LDS atomic per record in scatter and sort
-  // a bucket group of up to this many times kLocalSortCapacity records is streamed by ONE workgroup
-  // of pass 2; larger ones are cut into chunks shared by the workers of the chunked path
-  // (BLITZAR_AMD_SORT_STREAM_FACTOR, 1..16)
-  u32 sort_stream_factor = 16;
+  //
   // k_reduce_compact (the point addition at three places instead of ten: the code a wavefront walks
   // fits the instruction cache) instead of k_reduce.  Measured on both kinds of MI355X boxes
   // (profiles/round4_ab_compact_tails.log): where code beyond the instruction cache is fetched at half
@@ -216,70 +182,40 @@ struct msm_context {
   // BLITZAR_AMD_COMPACT_REDUCE: 0 never, 1 always, 2 (default) where the probe and the launch say so
   u32 compact_reduce = 2;
   bool slow_instruction_fetch = false;
-  hipStream_t make_stream(const std::vector<uint32_t>* mask = nullptr) {
-    hipStream_t s = nullptr;
-    if (mask != nullptr || dedicated_queues) {
-      std::vector<uint32_t> all;
-      if (mask == nullptr) {
-        int device = 0, cus = 0;
-        BZ_HIP_CHECK(hipGetDevice(&device));
-        BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-        all.assign((static_cast<u32>(cus) + 31) / 32, 0);
-        for (u32 i = 0; i < static_cast<u32>(cus); ++i) all[i / 32] |= 1u << (i % 32);
-        mask = &all;
-      }
-      if (hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>(mask->size()), mask->data()) ==
-          hipSuccess) {
-        return s;
-      }
-      (void)hipGetLastError();
-    }
-    BZ_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    return s;
-  }
-  void make_pipe_streams(bool null_caller) {
-    if (tail == nullptr) {
-      int least = 0, greatest = 0;
-      BZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      const int priority = tail_low_priority ? least : 0;
-      BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail, hipStreamNonBlocking, priority));
-      BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail2, hipStreamNonBlocking, priority));
-    }
-    // (the front / accumulation streams exist once the arrangement that uses them has been asked
-    // for: by the environment at context creation or by msm_context_set_overlap_front later)
-    if (null_caller || !overlap_front || front != nullptr) return;
+  // compute units a launch on `stream` may use (a caller's stream may carry a CU mask); queried once
+  // per stream handle.  k_group_sort_all's workers must all be resident at once.
+  hipStream_t cus_of_stream = nullptr;
+  u32 cus_available = 0;
+  u32 stream_cus(hipStream_t stream) {
+    if (cus_available != 0 && stream == cus_of_stream) return cus_available;
     int device = 0, cus = 0;
     BZ_HIP_CHECK(hipGetDevice(&device));
     BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    if (front_cus != 0 && cus >= 64 && front_cus * 2 <= static_cast<u32>(cus)) {
-      // disjoint CU sets (measured and rejected as the default: the front is CU-bound, not
-      // HBM-bound -- DESIGN.md section 7d).  Mask bit i -> XCC i mod 8 (kfd
-      // mqd_symmetrically_map_cu_mask): a contiguous range of bits is spread evenly over the XCDs
-      const u32 words = (static_cast<u32>(cus) + 31) / 32;
-      std::vector<uint32_t> fm(words, 0), am(words, 0);
-      const u32 split = static_cast<u32>(cus) - front_cus;
-      for (u32 i = 0; i < static_cast<u32>(cus); ++i) {
-        (i >= split ? fm : am)[i / 32] |= 1u << (i % 32);
-      }
-      front = make_stream(&fm);
-      acc = make_stream(&am);
-      return;
-    }
-    if (front_high_priority) {
-      int least = 0, greatest = 0;
-      BZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      BZ_HIP_CHECK(hipStreamCreateWithPriority(&front, hipStreamNonBlocking, greatest));
+    u32 usable = static_cast<u32>(cus);
+    uint32_t mask[32] = {};
+    if (stream != nullptr && hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
+      u32 bits = 0;
+      for (u32 w = 0; w < 32; ++w) bits += static_cast<u32>(__builtin_popcount(mask[w]));
+      if (bits != 0 && bits < usable) usable = bits;
     } else {
-      front = make_stream();
+      (void)hipGetLastError();
     }
-    acc = make_stream();
+    cus_of_stream = stream;
+    cus_available = usable == 0 ? 1 : usable;
+    return cus_available;
+  }
+  void make_pipe_streams() {
+    if (tail != nullptr) return;
+    int least = 0, greatest = 0;
+    BZ_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail, hipStreamNonBlocking, least));
+    BZ_HIP_CHECK(hipStreamCreateWithPriority(&tail2, hipStreamNonBlocking, least));
   }
   bool any_pending() const { return joined < seq; }
   // End of pipelined batch k: the caller's stream picks up the batch TWO before it (whose buffers
   // batch k reused, so it is long done): a pipelined result is complete on the stream once two
   // further calls have been enqueued, or after a flush.  (Waiting for the previous batch here
-  // would put its k_horner in front of whatever the caller enqueues next -- in the overlap_front
-  // arrangement: in front of the next call's entry mark, i.e. of the next front.)
+  // would put its k_horner in front of whatever the caller enqueues next.)
   void join_two_back(hipStream_t stream, u64 k) {
     if (k >= 2 && (joined < k - 1 || stream != joined_on)) {
       horner_done[(k - 2) & 3].wait(stream);
@@ -313,14 +249,12 @@ struct msm_context {
     for (auto& d : desc_dev) {
       if (d != nullptr) (void)hipFree(d);
     }
-    entry.destroy();
     for (int i = 0; i < 4; ++i) {
-      front_done[i].destroy();
       acc_done[i].destroy();
       reduce_done[i].destroy();
       horner_done[i].destroy();
     }
-    for (hipStream_t s : {front, acc, tail2, tail}) {
+    for (hipStream_t s : {tail2, tail}) {
       if (s != nullptr) (void)hipStreamDestroy(s);
     }
   }
@@ -355,11 +289,9 @@ static void configure_sort_kernels(msm_context& ctx) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_hist),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true, false>),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false, false>),
+  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   ctx.kernels_configured = true;
 }
@@ -367,9 +299,7 @@ static void configure_sort_kernels(msm_context& ctx) {
 // buffer sets of a batch (msm_context: throughput mode)
 struct pipe_mode {
   bool piped = false; // reduce + horner on the tail streams
-  bool split = false; // ... and front / accumulation on streams of their own
-  u32 front_sets() const { return split ? 2 : 1; }
-  u32 end_sets() const { return split ? 3 : (piped ? 2 : 1); }
+  u32 end_sets() const { return piped ? 2 : 1; }
   u32 tail_sets() const { return piped ? 2 : 1; }
 };
 
@@ -406,7 +336,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   tail += device_arena::padded(sizeof(point) * (num_tasks * partial_stride + 1));
   tail += device_arena::padded(sizeof(point) * (num_cols + 1));
   tail += device_arena::padded(sizeof(u32) * (num_tasks + 1));
-  return mode.front_sets() * front + mode.end_sets() * ends + mode.tail_sets() * tail;
+  return front + mode.end_sets() * ends + mode.tail_sets() * tail;
 }
 
 static inline u32 partial_stride_of(const msm_plan& plan) {
@@ -439,8 +369,6 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   for (const auto& c : cols) nonempty_columns += c.n != 0 ? 1 : 0;
   pipe_mode mode;
   mode.piped = ctx.defer_tail && ctx.overlap_tails && nonempty_columns < ctx.tuning.defer_max_columns;
-  // (the front / accumulation streams of overlap_front are blocking streams: not for the NULL stream)
-  mode.split = mode.piped && ctx.overlap_front && stream != nullptr;
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   tune.in_sequence = mode.piped;
@@ -498,26 +426,16 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     batches.push_back(std::move(plan));
     begin = end;
   }
-  if (mode.piped) ctx.make_pipe_streams(stream == nullptr);
+  if (mode.piped) ctx.make_pipe_streams();
   // a call outside the mode uses buffer set 0 on the caller's stream: everything pending first
   if (!mode.piped) ctx.join_all(stream);
   // one allocation sized for the largest batch: later resets never reallocate (no mid-call sync)
   if (need > ctx.arena.capacity()) ctx.join_all(stream); // the arena is about to be re-allocated
   ctx.arena.reset(need, stream);
-  // the front stream starts behind whatever the caller's stream holds now (operands ready)
-  if (mode.split) ctx.entry.record(stream);
   for (size_t k = 0; k < batches.size(); ++k) {
     ctx.arena.reset(need, stream);
     msm_enqueue_batch<C>(ctx, d_out + first_column[k] * static_cast<size_t>(out_stride), out_stride,
                          projective_out, batches[k], d_addends, d_api_generators, stream, mode);
-  }
-  // the operands have been consumed once the last front is through: the caller may overwrite
-  // them in stream order
-  // (resident addends -- generator sets, window tables, handle tables -- are read by the
-  // accumulation: a caller who frees or rewrites them in stream order must come behind that too)
-  if (mode.split && ctx.seq != 0) {
-    ctx.front_done[(ctx.seq - 1) & 3].wait(stream);
-    if (d_addends != nullptr) ctx.acc_done[(ctx.seq - 1) & 3].wait(stream);
   }
   ctx.mark_enqueued(stream);
 }
@@ -587,21 +505,17 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                 static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
                 static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
                 static_cast<u64>(d_addends == nullptr),
-                static_cast<u64>(mode.piped) | static_cast<u64>(mode.split) << 1}) {
+                static_cast<u64>(mode.piped)}) {
     layout = (layout ^ v) * 0x100000001b3ull;
   }
-  if (ctx.any_pending() && layout != ctx.pipe_layout) {
-    ctx.join_all(stream);
-    if (mode.split) ctx.entry.record(stream); // the front stream starts behind the join
-  }
+  if (ctx.any_pending() && layout != ctx.pipe_layout) ctx.join_all(stream);
   // this batch's place in the sequence, its buffer sets, its streams
   const u64 k = ctx.seq;
   const u32 parity = mode.piped ? static_cast<u32>(k & 1) : 0;
   const u32 end_set = mode.piped ? static_cast<u32>(k % mode.end_sets()) : 0;
-  hipStream_t fs = mode.split ? ctx.front : stream;
-  hipStream_t as = mode.split ? ctx.acc : stream;
+  hipStream_t fs = stream, as = stream; // front and accumulation: the caller's stream
   hipStream_t rs = mode.piped ? ctx.tail : stream;
-  hipStream_t hs = !mode.piped ? stream : (ctx.two_tail_streams ? ctx.tail2 : rs);
+  hipStream_t hs = mode.piped ? ctx.tail2 : stream;
   // completion marks of earlier batches (none outside the mode: join_all came first)
   auto earlier = [&](stage_mark* ring, u64 back) -> const stage_mark* {
     return mode.piped && k >= back ? &ring[(k - back) & 3] : nullptr;
@@ -609,7 +523,6 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   auto wait_for = [](const stage_mark* m, hipStream_t s) {
     if (m != nullptr) m->wait(s);
   };
-  if (mode.split) ctx.entry.wait(fs);
   char* desc = ctx.descriptor_block(parity, desc_bytes);
   if (image != ctx.desc_shadow[parity]) {
     wait_for(earlier(ctx.horner_done, 2), fs); // the last reader of this block
@@ -627,8 +540,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     // every column is empty: identities only, on the stream that carries every k_horner (in order
     // behind the previous batch's), behind the descriptor upload
     if (mode.piped) {
-      ctx.front_done[k & 3].record(fs);
-      ctx.front_done[k & 3].wait(hs);
+      ctx.acc_done[k & 3].record(fs);
+      ctx.acc_done[k & 3].wait(hs);
     }
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                        out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
@@ -650,7 +563,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   }
   const bool timing = ctx.timer.recording();
   // carve the arena: the same walk for every batch of a layout, this batch's sets picked out
-  for (u32 set = 0; set < mode.front_sets(); ++set) {
+  {
     addend* prepared = d_addends == nullptr ? ctx.arena.take<addend>(plan.max_rows + 1) : nullptr;
     i16* digits = ctx.arena.take<i16>(plan.total_entries + 8);
     u32* records = ctx.arena.take<u32>(plan.total_entries + 8);
@@ -663,20 +576,18 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     u32* big_tasks = big_barrier + 1;
     u32* bucket_count = ctx.arena.take<u32>(2 * (plan.total_buckets + 1));
     u32* segment_bucket = ctx.arena.take<u32>(plan.total_segments + 1);
-    if (set == (mode.split ? parity : 0)) {
-      b.addends = d_addends == nullptr ? prepared : d_addends;
-      b.digits = digits;
-      b.records = records;
-      b.sorted = sorted;
-      b.group_cursor = group_cursor;
-      b.arrivals = arrivals;
-      b.big_barrier = big_barrier;
-      b.group_start = group_start;
-      b.group_chunk = group_chunk;
-      b.big_tasks = big_tasks;
-      b.bucket_count = bucket_count;
-      b.segment_bucket = segment_bucket;
-    }
+    b.addends = d_addends == nullptr ? prepared : d_addends;
+    b.digits = digits;
+    b.records = records;
+    b.sorted = sorted;
+    b.group_cursor = group_cursor;
+    b.arrivals = arrivals;
+    b.big_barrier = big_barrier;
+    b.group_start = group_start;
+    b.group_chunk = group_chunk;
+    b.big_tasks = big_tasks;
+    b.bucket_count = bucket_count;
+    b.segment_bucket = segment_bucket;
   }
   for (u32 set = 0; set < mode.end_sets(); ++set) {
     u32* bucket_end = ctx.arena.take<u32>(plan.total_buckets + 1);
@@ -700,13 +611,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   const u32 seg_blocks =
       ceil_div_u32(plan.max_task_rows, static_cast<u64>(kAccumulateThreads) << plan.segment_log2);
 
-  // ---- front: on the caller's stream, or (throughput mode) beside the previous batch's
-  // accumulation on the front stream.  Its buffers were last read by the accumulation two batches
-  // ago, the bucket ends it rewrites by the reduce `end_sets` batches ago.
+  // ---- front: on the caller's stream, behind the previous batch's accumulation.  The bucket ends
+  // it rewrites were last read by the reduce `end_sets` batches ago.
   // (Overlapping stages of ONE call was measured in round 1 and is slower: k_accumulate's waves
   // hold 480 of a SIMD's 512 VGPRs, side kernels only get slots as they retire, and everything a
   // call runs feeds its next stage.)
-  wait_for(earlier(ctx.acc_done, 2), fs);
   wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
   // caller generators -> addends.  (Dealing this kernel's workgroups into the group sort's launch --
   // the one HBM-saturating kernel of the front inside the LDS-bound one -- was built and measured in
@@ -739,7 +648,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       return;
     }
     const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
-    if (rows32_c16 && ctx.fast_recode) {
+    if (rows32_c16) {
       hipLaunchKernelGGL(k_recode_rows32_c16, dim3(chunks, num_cols), dim3(256), 0, fs, b.digits,
                          b.cols, b.tasks, b.group_cursor, zero_words);
       return;
@@ -752,82 +661,34 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   u32 sort_launches = 0;
   ctx.timer.timed(timing, 2, fs, [&] {
     u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
-    const u32 stream_limit = ctx.sort_stream_factor * kLocalSortCapacity;
     // pass 1a (+ 1b in the last workgroup of every task)
     hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks,
-                       ctx.fuse_offsets ? b.arrivals : static_cast<u32*>(nullptr), b.group_start,
-                       b.group_chunk, b.bucket_count, bucket_fill, stream_limit);
-    sort_launches += 1;
-    if (!ctx.fuse_offsets) {
-      hipLaunchKernelGGL(k_group_offsets, dim3(num_tasks), dim3(256), 0, fs, b.group_cursor,
-                         b.group_start, b.group_chunk, b.bucket_count, bucket_fill, b.big_tasks,
-                         b.tasks, stream_limit);
-      sort_launches += 1;
-    }
-    // all tasks of a launch share one variant: staged unless some column needs the direct form
+                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks, b.arrivals,
+                       b.group_start, b.group_chunk, b.bucket_count, bucket_fill,
+                       kStreamedSortRecords);
+    // pass 1c; all tasks of a launch share one variant: staged unless some column needs the direct form
     if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
       const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
-      if (ctx.rank_once) {
-        hipLaunchKernelGGL((k_group_scatter<true, true>), dim3(plan.max_task_slices, num_tasks),
-                           dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
-                           b.tasks);
-      } else {
-        hipLaunchKernelGGL((k_group_scatter<true, false>), dim3(plan.max_task_slices, num_tasks),
-                           dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
-                           b.tasks);
-      }
+      hipLaunchKernelGGL((k_group_scatter<true>), dim3(plan.max_task_slices, num_tasks),
+                         dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
+                         b.tasks);
     } else {
-      hipLaunchKernelGGL((k_group_scatter<false, false>), dim3(plan.max_task_slices, num_tasks),
+      hipLaunchKernelGGL((k_group_scatter<false>), dim3(plan.max_task_slices, num_tasks),
                          dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
                          b.tasks);
     }
-    sort_launches += 1;
-    // pass 2; oversized groups (skewed digits) in the same launch or in two launches of their own
-    // -- either way they find nothing to do on uniform data
-    if (ctx.fuse_big != 0) {
-      const dim3 grid(plan.max_task_groups, num_tasks + 1);
-      auto launch_all = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(kGroupSortThreads), 0, fs, b.sorted, b.segment_bucket,
-                           b.bucket_end, b.records, b.group_start, b.group_chunk, b.tasks,
-                           num_tasks, b.bucket_count, bucket_fill, b.big_tasks, b.big_barrier);
-      };
-      if (ctx.fuse_big == 2) {
-        ctx.rank_once ? launch_all(k_group_sort_all<true, true>)
-                      : launch_all(k_group_sort_all<false, true>);
-      } else {
-        ctx.rank_once ? launch_all(k_group_sort_all<true, false>)
-                      : launch_all(k_group_sort_all<false, false>);
-        hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
-                           b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
-                           b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
-        sort_launches += 1;
-      }
-      sort_launches += 1;
-    } else {
-      const dim3 grid(plan.max_task_groups, num_tasks);
-      if (ctx.rank_once) {
-        hipLaunchKernelGGL((k_group_sort<true>), grid, dim3(kGroupSortThreads), 0, fs, b.sorted,
-                           b.segment_bucket, b.bucket_end, b.records, b.group_start, b.group_chunk,
-                           b.tasks);
-      } else {
-        hipLaunchKernelGGL((k_group_sort<false>), grid, dim3(kGroupSortThreads), 0, fs, b.sorted,
-                           b.segment_bucket, b.bucket_end, b.records, b.group_start, b.group_chunk,
-                           b.tasks);
-      }
-      hipLaunchKernelGGL(k_group_big_hist, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
-                         b.bucket_count, b.records, b.group_start, b.group_chunk, b.tasks,
-                         b.big_tasks);
-      hipLaunchKernelGGL(k_group_big_sort, dim3(kBigSortBlocks), dim3(kGroupSortThreads), 0, fs,
-                         b.sorted, b.segment_bucket, b.bucket_end, b.bucket_count, bucket_fill,
-                         b.records, b.group_start, b.group_chunk, b.tasks, b.big_tasks);
-      sort_launches += 3;
-    }
+    // pass 2, the oversized groups (skewed digits) in one more row of the same grid: their workers
+    // meet at a barrier, so there may only be as many as the stream's compute units hold at once
+    const u32 cus = ctx.stream_cus(fs);
+    const u32 workers = 2 * cus < kBigSortBlocks ? 2 * cus : kBigSortBlocks;
+    hipLaunchKernelGGL(k_group_sort_all, dim3(plan.max_task_groups, num_tasks + 1),
+                       dim3(kGroupSortThreads), 0, fs, b.sorted, b.segment_bucket, b.bucket_end,
+                       b.records, b.group_start, b.group_chunk, b.tasks, num_tasks, b.bucket_count,
+                       bucket_fill, b.big_tasks, b.big_barrier, workers);
+    sort_launches = 3;
   });
-  if (mode.split) ctx.front_done[k & 3].record(fs);
 
   // ---- accumulate: rewrites the bucket sums / head partials the reduce two batches ago read
-  if (mode.split) ctx.front_done[k & 3].wait(as);
   wait_for(earlier(ctx.reduce_done, 2), as);
   ctx.timer.timed(timing, 3, as, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,

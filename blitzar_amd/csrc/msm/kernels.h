@@ -6,10 +6,10 @@
 //   k_recode           scalars -> signed radix-2^c digits, transposed to [task][row] int16
 //                      (reference: mtxb digit extraction, sxt/multiexp/base/digit_utility.cc:27-98,
 //                       and the scalar transpose sxt/multiexp/base/scalar_array.cc:34-104)
-//   k_group_hist       per (task, slice of rows): LDS histogram of the digits by bucket *group*
-//   k_group_offsets    per task: exclusive scan of the group totals -> start of every group
+//   k_group_hist       per (task, slice of rows): LDS histogram of the digits by bucket *group*; the
+//                      last workgroup of a task scans the group totals -> start of every group
 //   k_group_scatter    per (task, slice): partition the digits into per-group runs of records
-//   k_group_sort       per (task, group; k_group_big_*: chunk of an oversized group): counting
+//   k_group_sort_all   per (task, group; one more grid row: the chunks of oversized groups): counting
 //                      sort by bucket inside LDS -> `row | sign << 31` list, bucket end offsets,
 //                      segment -> bucket map
 //                      (together a two-pass radix sort by bucket; reference K1/K2:
@@ -391,8 +391,8 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
 }
 
 //--------------------------------------------------------------------------------------------------
-// sort by bucket: k_group_hist -> k_group_offsets -> k_group_scatter (partition by bucket group)
-// -> k_group_sort (counting sort of one group inside LDS)
+// sort by bucket: k_group_hist (+ the scan of the group totals) -> k_group_scatter (partition by
+// bucket group) -> k_group_sort_all (counting sort of one group inside LDS)
 //--------------------------------------------------------------------------------------------------
 // Both partition sweeps visit the digits of a (task, slice) in the same vectorised order.  `fn(r, e)`
 // is called for every non-zero stored digit e = -D of row r (relative to the slice).
@@ -416,8 +416,9 @@ __device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig
 
 // chunks an oversized group of `total` records is cut into in pass 2 (0: one workgroup sorts it)
 // `stream_limit` = records up to which ONE workgroup streams a group through LDS in rounds of
-// kLocalSortCapacity (msm_context::sort_stream_factor x the capacity); beyond it the group goes to
-// the chunked path, whose workers share its chunks
+// kLocalSortCapacity (16 x the capacity: sending such groups to the chunked path earlier was measured
+// twice and is slower, profiles/round4_ab_sort_stream_limit.log); beyond it the group goes to the
+// chunked path, whose workers share its chunks
 constexpr u32 kStreamedSortRecords = 16 * kLocalSortCapacity;
 __device__ __forceinline__ u32 big_chunks_of(u32 total, u32 stream_limit) {
   return total <= stream_limit ? 0 : (total + kLocalSortCapacity - 1) / kLocalSortCapacity;
@@ -429,8 +430,8 @@ __device__ __forceinline__ u32 big_chunks_of(u32 total, u32 stream_limit) {
 //   group_chunk[task.group_base + g] = chunks of the oversized groups before g, entry [G] = their
 //   number (all zero on uniform digits); the bucket counters of oversized groups are cleared and
 //   the task is appended to big_tasks (big_tasks[0] = their count, zeroed by the recode kernel).
-// The totals are read with agent-scope loads: in the fused form (below) they were written by
-// atomics of other workgroups of the SAME launch.
+// The totals are read with agent-scope loads: they were written by atomics of other workgroups of
+// the SAME launch (k_group_hist below).
 template <u32 T>
 __device__ __forceinline__ void
 group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ group_cursor,
@@ -481,7 +482,7 @@ group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ gro
       cur[g] = base + incl - total;
       gc[g] = chunk_base + chunk_incl - chunks;
       if (chunks != 0) {
-        // an oversized group: its chunks meet in these counters (k_group_big_hist / _sort)
+        // an oversized group: its chunks meet in these counters (big_hist_body / big_sort_body)
         const u64 first = task.bucket_base + (static_cast<u64>(g) << task.group_bits);
         for (u32 b = 0; b < (1u << task.group_bits); ++b) {
           bucket_count[first + b] = 0;
@@ -502,9 +503,8 @@ group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ gro
 
 // Pass 1a.  group_total[task.group_base + g] += digits of the slice whose bucket lies in group g
 // (2^s consecutive buckets): LDS histogram, one global atomic per populated group.
-// `arrivals` != nullptr: the fused form -- the workgroup that finishes LAST on a task (a ticket per
-// task, zeroed with the group cursors by the recode kernel) goes on to run pass 1b for it, so
-// k_group_offsets and its ~5 us of a 17-workgroup launch disappear from the call.
+// The workgroup that finishes LAST on a task (a ticket per task, zeroed with the group cursors by
+// the recode kernel) goes on to run pass 1b for it: no 17-workgroup launch of its own (~5 us).
 static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_hist(u32* __restrict__ group_total, u32* __restrict__ big_tasks,
                  const i16* __restrict__ digits, const task_desc* __restrict__ tasks,
@@ -534,13 +534,15 @@ static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two wo
   for (u32 g = tid; g < groups; g += kSortThreads) {
     if (lds[g] != 0) atomicAdd(&out[g], lds[g]);
   }
-  if (arrivals == nullptr) return;
   // No fences: the group totals are only ever touched by agent-scope atomics (performed at the
-  // device's coherence point, not in an XCD's L2) and read back with agent-scope atomic loads, and
-  // the barrier below waits until every atomic of this workgroup has been acknowledged before the
-  // ticket is taken.  (A __threadfence() per lane here is an L2 write-back + invalidate per
-  // wavefront on a part whose eight L2s are not coherent with each other: measured, it took this
-  // kernel from 11 to 600 us.)
+  // device's coherence point, not in an XCD's L2) and read back with agent-scope atomic loads.
+  // Hardware assumption, stated: on gfx950 an atomic without return counts in vmcnt until the
+  // coherence point has acknowledged it, so every wavefront drains vmcnt explicitly before the
+  // barrier behind which the ticket is taken (the HIP memory model alone would ask for a release /
+  // acquire pair here; a __threadfence() per lane is an L2 write-back + invalidate per wavefront on
+  // a part whose eight L2s are not coherent with each other: measured, it took this kernel from 11
+  // to 600 us).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     const u32 ticket = __hip_atomic_fetch_add(&arrivals[blockIdx.y], 1u, __ATOMIC_RELAXED,
@@ -552,18 +554,6 @@ static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two wo
   group_offsets_block<kSortThreads>(task, blockIdx.y, group_total, group_start, group_chunk,
                                     bucket_count, bucket_fill, big_tasks, wave_sums, wave_chunks,
                                     stream_limit);
-}
-
-static __global__ void __launch_bounds__(256)
-    k_group_offsets(u32* __restrict__ group_cursor, u32* __restrict__ group_start,
-                    u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
-                    u32* __restrict__ bucket_fill, u32* __restrict__ big_tasks,
-                    const task_desc* __restrict__ tasks, u32 stream_limit) {
-  __shared__ u32 wave_sums[4];
-  __shared__ u32 wave_chunks[4];
-  const task_desc task = tasks[blockIdx.x];
-  group_offsets_block<256>(task, blockIdx.x, group_cursor, group_start, group_chunk, bucket_count,
-                           bucket_fill, big_tasks, wave_sums, wave_chunks, stream_limit);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
@@ -591,14 +581,13 @@ __device__ __forceinline__ void unpack_digits(const uint4& pack, int e[8]) {
 // variant (more than kMaxStagedGroups groups: columns beyond ~2^25 rows) stores records one by
 // one.  Per vector the eight cursor bumps are issued before the eight dependent stores.
 //   dynamic LDS: Staged ? 3 * groups + 1 + kStagedSliceRows : groups   words
-// RankOnce (Staged only: every digit vector of the slice is held in registers): the counting pass
-// keeps what its atomic returns -- the digit's rank inside its group -- and the second pass places
+// Staged slices are short enough for every digit vector to stay in registers, so the counting pass
+// keeps what its LDS atomic returns -- the digit's rank inside its group -- and the second pass places
 // the record at local_start[group] + rank with a plain LDS read instead of a second atomic.
-template <bool Staged, bool RankOnce = false>
+template <bool Staged>
 __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_scatter(u32* __restrict__ records, u32* __restrict__ group_cursor,
                     const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
-  static_assert(Staged || !RankOnce);
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   __shared__ u32 wave_sums[kSortThreads / 64];
   const task_desc task = tasks[blockIdx.y];
@@ -625,7 +614,8 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
     return v == tid ? held[0] : (v == tid + kSortThreads ? held[1] : dig4[v]);
   };
   u32 rank[2][8];
-  if constexpr (RankOnce) {
+  if constexpr (Staged) {
+    static_assert(kStagedSliceRows <= 2 * 8 * kSortThreads);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const u32 v = tid + static_cast<u32>(j) * kSortThreads;
@@ -665,7 +655,6 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
     u32 start = incl - count;
     for (u32 w = 0; w < wave; ++w) start += wave_sums[w];
     if (tid < groups) {
-      cursor[tid] = start;
       local_start[tid] = start;
       run_base[tid] = count != 0 ? atomicAdd(&cur[tid], count) : 0;
       if (tid + 1 == groups) local_start[groups] = start + count;
@@ -679,7 +668,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   lds_barrier();
   u32* out = records + task.entry_base;
   const u32 in_group = (1u << s) - 1, shift = 31 - s;
-  if constexpr (RankOnce) {
+  if constexpr (Staged) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const u32 v = tid + static_cast<u32>(j) * kSortThreads;
@@ -689,6 +678,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       bool take[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
+        // E = -D: positive E means the digit is negative -> subtract the generator
         const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
         take[k] = v * 8 + k < rows && e[k] != 0;
         rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
@@ -700,6 +690,12 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
         if (take[k]) staging[pos[k]] = rec[k];
       }
     }
+    lds_barrier();
+    for (u32 g = wave; g < groups; g += kSortThreads / 64) {
+      const u32 from = local_start[g], count = local_start[g + 1] - from;
+      u32* dst = out + run_base[g];
+      for (u32 i = lane; i < count; i += 64) dst[i] = staging[from + i];
+    }
   } else {
     for (u32 v = tid; v < nvec; v += kSortThreads) {
       int e[8];
@@ -708,7 +704,6 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       bool take[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        // E = -D: positive E means the digit is negative -> subtract the generator
         const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
         take[k] = v * 8 + k < rows && e[k] != 0;
         rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
@@ -718,22 +713,8 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (take[k]) {
-          if constexpr (Staged) {
-            staging[pos[k]] = rec[k];
-          } else {
-            out[pos[k]] = rec[k];
-          }
-        }
+        if (take[k]) out[pos[k]] = rec[k];
       }
-    }
-  }
-  if constexpr (Staged) {
-    lds_barrier();
-    for (u32 g = wave; g < groups; g += kSortThreads / 64) {
-      const u32 from = local_start[g], count = local_start[g + 1] - from;
-      u32* dst = out + run_base[g];
-      for (u32 i = lane; i < count; i += 64) dst[i] = staging[from + i];
     }
   }
 }
@@ -742,23 +723,23 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
 //   sorted[task.entry_base + pos] = row | (digit negative) << 31, grouped by bucket;
 //   bucket_end[task.bucket_base + b] = end offset of bucket b in the task's sorted list;
 //   segment_bucket[task.segment_base + pos / 32] = bucket of the entry that starts a segment.
-// k_group_sort, one workgroup per (task, group): a group of at most kLocalSortCapacity records
+// One workgroup per (task, group): a group of at most kLocalSortCapacity records
 // (nearly every group, on uniform digits) is held in registers, count -> scan -> rank run in LDS, the
 // group's piece of the sorted list is assembled in LDS and written out in order (coalesced).
 // Up to 16 times that (a window whose digits use few of its buckets, like the top one) the
 // workgroup streams its records twice and writes its piece directly.
 // A larger group still (skewed digits: constants, booleans; very long columns) is cut into chunks of
-// kLocalSortCapacity records that cooperate through global memory, in two small launches whose
-// workgroups loop over the chunks (nothing to do on uniform digits):
-//   k_group_big_hist  adds every chunk's bucket histogram into bucket_count,
-//   k_group_big_sort  scans the group's bucket counts, claims a run per (chunk, bucket) with an
-//                     atomic on bucket_fill, sorts the chunk in LDS and copies the runs out.
+// kLocalSortCapacity records that cooperate through global memory; the workers of one more grid row
+// loop over the chunks in two phases (nothing to do on uniform digits):
+//   big_hist_body  adds every chunk's bucket histogram into bucket_count,
+//   big_sort_body  scans the group's bucket counts, claims a run per (chunk, bucket) with an
+//                  atomic on bucket_fill, sorts the chunk in LDS and copies the runs out.
 // Equal keys of a wavefront are combined before they touch an LDS counter (wave_aggregated_add):
 // on skewed data all 64 lanes hit the same counter, which would serialise them.
 constexpr u32 kGroupSortThreads = 512;
 constexpr u32 kLocalSortPerThread = kLocalSortCapacity / kGroupSortThreads;
-constexpr u32 kBigSortBlocks = 128; // workgroups that share the chunks of the oversized groups
-                                    // (they loop; even empty ones cost ~35 ns each to dispatch)
+constexpr u32 kBigSortBlocks = 128; // at most this many workgroups share the chunks of the
+                                    // oversized groups (they loop)
 static_assert(kLocalSortPerThread * kGroupSortThreads == kLocalSortCapacity);
 static_assert(2 * kGroupSortThreads >= (1u << kMaxGroupBits));
 
@@ -773,9 +754,8 @@ struct big_sort_lds {
   u32 local_start[1u << kMaxGroupBits]; // first staged entry of the bucket
 };
 
-// RankOnce: the counting pass keeps the rank its atomic returns, the placing pass adds the bucket's
-// start with a plain LDS read (one LDS atomic per record instead of two).
-template <bool RankOnce>
+// The counting pass keeps the rank its atomic returns, the placing pass adds the bucket's start with
+// a plain LDS read (one LDS atomic per record instead of two).
 __device__ __forceinline__ void
 group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
                  u32* __restrict__ segment_bucket, u32* __restrict__ bucket_end,
@@ -797,7 +777,7 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
   const u32 in_group = buckets - 1, shift = 31 - s, row_mask = (1u << shift) - 1;
   const bool staged = total <= kLocalSortCapacity; // uniform over the workgroup
   u32 mine[kLocalSortPerThread];
-  // RankOnce: ranks inside the bucket (< kLocalSortCapacity < 2^16), two per register
+  // ranks inside the bucket (< kLocalSortCapacity < 2^16), two per register
   u32 rank2[(kLocalSortPerThread + 1) / 2];
   if (staged) {
 #pragma unroll
@@ -807,20 +787,14 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
     }
 #pragma unroll
     for (u32 k = 0; k < kLocalSortPerThread; ++k) {
-      if constexpr (RankOnce) {
-        u32 r = 0;
-        if (tid + k * kGroupSortThreads < total) {
-          r = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
-        }
-        if ((k & 1) == 0) {
-          rank2[k / 2] = r;
-        } else {
-          rank2[k / 2] |= r << 16;
-        }
+      u32 r = 0;
+      if (tid + k * kGroupSortThreads < total) {
+        r = atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
+      }
+      if ((k & 1) == 0) {
+        rank2[k / 2] = r;
       } else {
-        if (tid + k * kGroupSortThreads < total) {
-          atomicAdd(&cursor[(mine[k] >> shift) & in_group], 1u);
-        }
+        rank2[k / 2] |= r << 16;
       }
     }
   } else {
@@ -876,11 +850,7 @@ group_sort_block(u32 g, const task_desc& task, u32* __restrict__ sorted,
       at[k] = 0;
       if (tid + k * kGroupSortThreads < total) {
         const u32 b = (mine[k] >> shift) & in_group;
-        if constexpr (RankOnce) {
-          at[k] = cursor[b] + ((rank2[k / 2] >> (16 * (k & 1))) & 0xffffu);
-        } else {
-          at[k] = atomicAdd(&cursor[b], 1u);
-        }
+        at[k] = cursor[b] + ((rank2[k / 2] >> (16 * (k & 1))) & 0xffffu);
       }
     }
 #pragma unroll
@@ -1130,88 +1100,53 @@ big_sort_body(u32 worker, u32 workers, u32* __restrict__ sorted, u32* __restrict
   }
 }
 
-template <bool RankOnce>
-__global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: four workgroups per CU
-    k_group_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                 u32* __restrict__ bucket_end, const u32* __restrict__ records,
-                 const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                 const task_desc* __restrict__ tasks) {
-  __shared__ sort_lds lds;
-  const task_desc task = tasks[blockIdx.y];
-  group_sort_block<RankOnce>(blockIdx.x, task, sorted, segment_bucket, bucket_end, records,
-                             group_start, group_chunk, lds);
-}
-
-static __global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_big_hist(u32* __restrict__ bucket_count, const u32* __restrict__ records,
-                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
-  __shared__ u32 cursor[1u << kMaxGroupBits];
-  big_hist_body(blockIdx.x, gridDim.x, bucket_count, records, group_start, group_chunk, tasks,
-                big_tasks, big_tasks[0], cursor);
-}
-
-static __global__ void __launch_bounds__(kGroupSortThreads)
-    k_group_big_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
-                     u32* __restrict__ bucket_end, const u32* __restrict__ bucket_count,
-                     u32* __restrict__ bucket_fill, const u32* __restrict__ records,
-                     const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
-                     const task_desc* __restrict__ tasks, const u32* __restrict__ big_tasks) {
-  __shared__ sort_lds lds;
-  __shared__ big_sort_lds big;
-  big_sort_body(blockIdx.x, gridDim.x, sorted, segment_bucket, bucket_end, bucket_count,
-                bucket_fill, records, group_start, group_chunk, tasks, big_tasks, big_tasks[0], lds,
-                big);
-}
-
 // Pass 2 with the oversized groups inside the same launch: one more row of the grid
-// (blockIdx.y == num_tasks), whose first kBigSortBlocks workgroups are the workers of the chunked
-// path.  They return at once when no task has an oversized group (uniform digits: big_tasks[0] was
-// settled by pass 1b), and an empty launch of a separate kernel, ~4.5 us, is gone from the call.
-//   BigSortToo = false: phase 1 (the histograms) only; k_group_big_sort stays a launch of its own;
-//   BigSortToo = true: both phases, separated by a barrier among the workers (a counter in global
-//     memory, zeroed by the recode kernel): at most 128 workgroups of 512 threads and 36 KiB of LDS,
-//     which the machine holds at once whatever else of this launch is resident, and every other
-//     workgroup of the launch terminates on its own, so all workers get dispatched.  Phase 2 needs
-//     ~100 VGPRs; inside this kernel's budget of 64 (four workgroups per CU for pass 2 proper) it
-//     spills a little, on the skewed path only.
-template <bool RankOnce, bool BigSortToo>
-__global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: four workgroups per CU
+// (blockIdx.y == num_tasks), whose first `workers` workgroups run the chunked path.  They return at
+// once when no task has an oversized group (uniform digits: big_tasks[0] was settled by pass 1b).
+// The two phases of that path are separated by a barrier among the workers (a counter in global
+// memory, zeroed by the recode kernel), so ALL `workers` workgroups must be resident at once: the host
+// sizes `workers` from the compute units the launch stream may use (engine.h: at most kBigSortBlocks,
+// two per available CU -- 512 threads and 36 KiB of LDS each, four fit a CU), and every other
+// workgroup of the launch terminates on its own, so the workers do get dispatched.  Phase 2 needs
+// ~100 VGPRs; inside this kernel's budget of 64 (four workgroups per CU for pass 2 proper) it spills
+// a little, on the skewed path only.
+static __global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: four workgroups per CU
     k_group_sort_all(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
                      u32* __restrict__ bucket_end, const u32* __restrict__ records,
                      const u32* __restrict__ group_start, const u32* __restrict__ group_chunk,
                      const task_desc* __restrict__ tasks, u32 num_tasks,
                      u32* __restrict__ bucket_count, u32* __restrict__ bucket_fill,
-                     const u32* __restrict__ big_tasks, u32* __restrict__ big_barrier) {
+                     const u32* __restrict__ big_tasks, u32* __restrict__ big_barrier,
+                     u32 max_workers) {
   __shared__ sort_lds lds;
   if (blockIdx.y < num_tasks) {
     const task_desc task = tasks[blockIdx.y];
-    group_sort_block<RankOnce>(blockIdx.x, task, sorted, segment_bucket, bucket_end, records,
-                               group_start, group_chunk, lds);
+    group_sort_block(blockIdx.x, task, sorted, segment_bucket, bucket_end, records, group_start,
+                     group_chunk, lds);
     return;
   }
-  const u32 workers = gridDim.x < kBigSortBlocks ? gridDim.x : kBigSortBlocks;
+  const u32 workers = gridDim.x < max_workers ? gridDim.x : max_workers;
   if (blockIdx.x >= workers) return;
   const u32 num_big_tasks = big_tasks[0];
   if (num_big_tasks == 0) return;
   big_hist_body(blockIdx.x, workers, bucket_count, records, group_start, group_chunk, tasks,
                 big_tasks, num_big_tasks, lds.cursor);
-  if constexpr (BigSortToo) {
-    __shared__ big_sort_lds big;
-    // (the histogram counters are touched by agent-scope atomics only and read back with
-    // agent-scope loads; the barrier waits for this workgroup's atomics: no fences, see k_group_hist)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(big_barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(big_barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < workers) {
-        __builtin_amdgcn_s_sleep(16);
-      }
+  __shared__ big_sort_lds big;
+  // The histogram counters are touched by agent-scope atomics only and read back with agent-scope
+  // loads.  Same hardware assumption as k_group_hist's ticket: an atomic counts in vmcnt until the
+  // coherence point has acknowledged it, so every wavefront drains vmcnt before the workgroup takes
+  // its place at the barrier; no L2 write-back / invalidate per wavefront.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(big_barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(big_barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < workers) {
+      __builtin_amdgcn_s_sleep(16);
     }
-    __syncthreads();
-    big_sort_body(blockIdx.x, workers, sorted, segment_bucket, bucket_end, bucket_count,
-                  bucket_fill, records, group_start, group_chunk, tasks, big_tasks, num_big_tasks,
-                  lds, big);
   }
+  __syncthreads();
+  big_sort_body(blockIdx.x, workers, sorted, segment_bucket, bucket_end, bucket_count, bucket_fill,
+                records, group_start, group_chunk, tasks, big_tasks, num_big_tasks, lds, big);
 }
 
 //--------------------------------------------------------------------------------------------------

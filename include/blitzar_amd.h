@@ -110,12 +110,10 @@ uint64_t bzamd_stage_timing_collect(double* out_ms);
  * stage at ONE workgroup per column (~250 dependent doublings, the encoding's 250 squarings).
  * bzamd_pipeline_next() makes the NEXT MSM enqueued through a device entry point of this header
  * (bzamd_msm_device*, bzamd_fixed_packed_multiexponentiation_device) on the current device run its
- * stages on internal streams of the engine, where the front of call k + 1 runs beside the
- * accumulation of call k and the tails of call k - 1 (the calls must have the same shape to
- * overlap: the engine otherwise simply waits).  The caller's `stream` only orders the call: its
- * front starts behind whatever the stream holds when the call is made (the operands are ready),
- * and the stream waits for that front (the operands may be overwritten in stream order right after
- * the call returns).  The commitments of such a call are complete on `stream` only once TWO later
+ * two tail stages on internal streams of the engine, beside the front and the accumulation of call
+ * k + 1, which stay on the caller's `stream` (the calls must have the same shape to overlap: the
+ * engine otherwise simply waits).  The operands are consumed in stream order, as without the mode.
+ * The commitments of such a call are complete on `stream` only once TWO later
  * such calls on the device have been enqueued on it, or after bzamd_pipeline_flush(stream): do not
  * read them earlier.  Calls with 64 or more columns ignore the request (their tails fill the
  * machine).  A pipelined sequence lives on ONE stream and one caller thread per device (the NULL
@@ -124,19 +122,6 @@ uint64_t bzamd_stage_timing_collect(double* out_ms);
  * (Measured on MI355X, 2^20 curve25519 rows: see DESIGN.md section 9.) */
 void bzamd_pipeline_next(void);
 void bzamd_pipeline_flush(void* stream);
-/* Where the front of a pipelined call (conversion of caller generators, recoding, sort) runs on the
- * current device: 0 (default) on the caller's stream, behind the accumulation of the previous call;
- * 1..3 on an internal stream BESIDE that accumulation -- 1: a high-priority front stream and an
- * accumulation stream with a hardware queue of its own, 2: two plain streams, 3: a high-priority front
- * stream and a plain accumulation stream.  Which one is fastest depends on how the process's streams
- * share the device's hardware queues, not on the data: measured on MI355X at config 2, ms per step --
- * in a PyTorch process with its stream pool 0.976 / 0.948 / 0.938 / 0.945 for 0 / 1 / 2 / 3, in a process
- * with a single stream 0.975 / 0.994 / 1.24 / 0.992 (profiles/round4_front_arrangements.txt).  A caller
- * that cares measures them once per process and keeps the best (bench.py does).  Call with nothing
- * pending (after bzamd_pipeline_flush); callers on the NULL stream are never split.  Operand and
- * result rules of the mode do not change. */
-void bzamd_pipeline_arrangement(uint32_t arrangement);
-
 
 /* Variable-base MSM on device-resident operands.
  *   commitments  DEVICE  num_sequences canonical encodings (32 / 48 / 72 / 72 bytes each)

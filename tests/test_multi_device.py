@@ -227,12 +227,10 @@ PIPELINE_BENCH = os.path.join(ROOT, "tools", "pipeline_bench", "_build", "pipeli
 
 @pytest.mark.gpu
 def test_stream_arrangements_of_the_throughput_mode_agree():
-    """the knobs that move the stages of consecutive calls between streams (read once per context,
-    hence one native process each: tools/pipeline_bench): never forking, one tail stream, tails at
-    normal priority, the measured-and-rejected front / accumulation streams with a priority queue
-    or with CU masks, the NULL stream as the caller's -- every step of every arrangement must
-    produce the same commitments as plain calls (the tool checks the steps against each other and
-    prints a hash over them)"""
+    """the throughput mode against plain calls (knobs are read once per context, hence one native
+    process each: tools/pipeline_bench): never forking, the default, the NULL stream as the caller's,
+    and both forms of the bucket reduction -- every step of every variant must produce the same
+    commitments (the tool checks the steps against each other and prints a hash over them)"""
     if not os.path.exists(PIPELINE_BENCH):  # normally built by __graft_entry__.build()
         src_dir = os.path.dirname(os.path.dirname(PIPELINE_BENCH))
         lib_dir = os.path.join(ROOT, "blitzar_amd", "lib")
@@ -245,16 +243,8 @@ def test_stream_arrangements_of_the_throughput_mode_agree():
         ({"BLITZAR_AMD_OVERLAP_TAILS": "0"}, []),
         ({}, []),
         ({}, ["--null-stream"]),
-        ({"BLITZAR_AMD_TAIL_STREAMS": "1"}, []),
-        ({"BLITZAR_AMD_TAIL_LOW_PRIORITY": "0"}, []),
-        ({"BLITZAR_AMD_OVERLAP_FRONT": "1"}, []),
-        ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_PRIORITY": "0",
-          "BLITZAR_AMD_DEDICATED_QUEUES": "0"}, []),
-        ({"BLITZAR_AMD_OVERLAP_FRONT": "1", "BLITZAR_AMD_FRONT_CUS": "64"}, []),
-        # the round-3 forms of the sort's front (round 4 fused them; kept as A/B knobs)
-        ({"BLITZAR_AMD_FUSE_OFFSETS": "0"}, []),
-        ({"BLITZAR_AMD_FUSE_BIG": "1"}, []),
-        ({"BLITZAR_AMD_FUSE_BIG": "0", "BLITZAR_AMD_RANK_ONCE": "0"}, []),
+        ({"BLITZAR_AMD_COMPACT_REDUCE": "0"}, []),
+        ({"BLITZAR_AMD_COMPACT_REDUCE": "1"}, []),
     ]
     # (2^19 rows x 16 windows: long enough for the throughput mode's own reduce geometry, plan.h)
     # (--skew: two rows in three hold one scalar -- oversized bucket groups, the chunked sort path
