@@ -202,6 +202,19 @@ def profile_json(name):
     return {}
 
 
+IN_RUN_ALU = {}  # filled by probe_alu(): the v_mad_u64_u32 issue rate of THIS box, measured in this run
+
+
+def probe_alu(lib, target_ms=50.0):
+    """v_mad_u64_u32 issue rate of this device now (bzamd_probe_mad_rate: all SIMDs at 8 waves for
+    ~50 ms, the last 4 ms launch measured); profiles/alu_calibration.json stays the fallback"""
+    out = (ctypes.c_double * 4)()
+    if lib.bzamd_probe_mad_rate(target_ms, out) != 0 or out[0] <= 0:
+        return None
+    return {"wave_instructions_per_s": out[0], "effective_clock_hz": out[1],
+            "cycles_per_wave_instruction": out[2], "load_ms": out[3]}
+
+
 def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
     """HBM roofline of the dominant kernel (algorithmic bytes over its HIP-event duration), plus --
     from the committed rocprofv3 PMC passes of this command (profiles/roofline_traffic.json) and the
@@ -221,13 +234,24 @@ def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
         roof["valu_wave_instructions_per_launch"] = pmc.get("sq_insts_valu_per_launch")
     isa = profile_json("isa_counts.json").get("kernels", {}).get(kernel)
     if isa and additions and accumulate_ms > 0:
-        cal = alu_calibration()
-        clock_hz = cal.get("effective_clock_hz", EFFECTIVE_CLOCK_HZ)
-        issue = cal.get("mad_u64_u32_cycles", MAD_ISSUE_CYCLES)
         mads = isa["mads_per_addition"]
         wave_mads = additions * mads / 64
-        peak = SIMDS * clock_hz / issue
         dur_s = accumulate_ms * 1e-3
+        if IN_RUN_ALU.get("before"):
+            # this box, this run: the mean of the probes right before the warm-up and right after
+            # the timed region
+            probes = [IN_RUN_ALU[k] for k in ("before", "after") if IN_RUN_ALU.get(k)]
+            peak = sum(p["wave_instructions_per_s"] for p in probes) / len(probes)
+            clock_hz = sum(p["effective_clock_hz"] for p in probes) / len(probes)
+            issue = sum(p["cycles_per_wave_instruction"] for p in probes) / len(probes)
+            peak_source = ("in-run: bzamd_probe_mad_rate on this device (all SIMDs at 8 waves, ~50 ms), "
+                           "mean of the probes before the warm-up and after the timed region")
+        else:
+            cal = alu_calibration()
+            clock_hz = cal.get("effective_clock_hz", EFFECTIVE_CLOCK_HZ)
+            issue = cal.get("mad_u64_u32_cycles", MAD_ISSUE_CYCLES)
+            peak = SIMDS * clock_hz / issue
+            peak_source = "fallback: profiles/alu_calibration.json (another box, round 2)"
         roof["alu"] = {"instruction": "v_mad_u64_u32", "per_addition": mads,
                        "valu_instructions_per_addition_isa": isa["loop_valu"],
                        "bucket_additions_per_launch": additions,
@@ -236,8 +260,14 @@ def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
                        "issue_cycles": issue, "effective_clock_hz": clock_hz,
                        "frac": wave_mads / dur_s / peak,
                        "ps_per_addition": dur_s / additions * 1e12,
-                       "source": "profiles/isa_counts.json (tools/prof/isa_count.py), "
-                                 "profiles/alu_calibration.json"}
+                       "peak_source": peak_source,
+                       "source": "instruction counts: profiles/isa_counts.json (tools/prof/isa_count.py)"}
+        # the driver's record keeps the scalars of `roofline`, not its nested objects
+        roof["alu_frac"] = roof["alu"]["frac"]
+        roof["alu_peak_wave_mads_per_s"] = peak
+        roof["alu_effective_clock_hz"] = clock_hz
+        roof["alu_peak_in_run"] = bool(IN_RUN_ALU.get("before"))
+        roof["alu_mads_per_addition"] = mads
         if pmc and pmc.get("sq_insts_valu_per_launch"):
             roof["alu"]["valu_instructions_per_addition_pmc"] = (
                 pmc["sq_insts_valu_per_launch"] * 64 / additions)
@@ -601,31 +631,83 @@ def in_process_multi_device():
         return {"error": repr(exc)[:300]}
 
 
-def device_state(lib, sequence_call, lone_call, stream):
-    """which box this is and what the part does under the bench's two kinds of load (tools/prof/
-    device_state.py: amd-smi / rocm-smi): idle, beside a sequence of the timed region's calls (every
-    SIMD busy: the package power limit governs the clock), and beside lone calls (40 % of a lone call
-    are single-wavefront tails).  The SMI tools take ~1 s per sample, so each load is kept up for a
-    few seconds by enqueueing ahead; untimed, after everything that is measured."""
+class SmiTrace:
+    """tools/prof/smi_trace.py in a process of its own: a >= 10 Hz (asked: 50 Hz) trace of socket
+    power, the shader clock of every XCD and the part's energy accumulator through the amdsmi
+    library, sliced afterwards by the wall-clock windows of the bench's legs"""
+
+    def __init__(self):
+        import subprocess
+        import tempfile
+        self.path = os.path.join(tempfile.gettempdir(), f"bzamd_smi_trace_{os.getpid()}.jsonl")
+        self.proc = None
+        self.windows = {}
+        try:
+            self.proc = subprocess.Popen(
+                [sys.executable, os.path.join(ROOT, "tools", "prof", "smi_trace.py"), "--hz", "50",
+                 "--out", self.path, "--max-seconds", "900"],
+                stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def window(self, name, t0, t1):
+        self.windows[name] = (t0, t1)
+
+    def finish(self):
+        sys.path.insert(0, os.path.join(ROOT, "tools", "prof"))
+        import smi_trace
+        if self.proc is not None:
+            try:
+                self.proc.stdin.close()
+                self.proc.wait(timeout=10)
+            except Exception:
+                self.proc.kill()
+        static, samples, errors = smi_trace.load(self.path)
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+        out = {"static": static, "samples": len(samples)}
+        if errors:
+            out["errors"] = errors[:3]
+        for name, (t0, t1) in self.windows.items():
+            out[name] = smi_trace.summarize(samples, t0, t1)
+        return out
+
+
+def device_state(lib, sequence_call, lone_call, stream, trace):
+    """which box this is and what the part does under the bench's two kinds of load: a sequence of
+    the timed region's calls (every SIMD busy) and lone calls (40 % of a lone call are
+    single-wavefront tails), each kept up for seconds and traced at 50 Hz by `trace` (SmiTrace);
+    idle before.  Untimed, after everything that is measured.  The sequence leg is also the long-run
+    figure of the step: `sustained_ms_per_step` over its last 2500 calls."""
     sys.path.insert(0, os.path.join(ROOT, "tools", "prof"))
     import device_state as smi
     import threading
-    out = {"static": smi.static_info(), "idle": smi.sample(),
-           # the library's own probe (which of the pool's two kinds of boxes this is, DESIGN section 9)
+    out = {"static_cli": smi.static_info(),
+           # the library's own probe (which of the pool's two kinds of boxes this is)
            "instruction_fetch_beyond_the_icache": {1: "half speed (the slower kind of box)",
                                                    0: "full speed (the faster kind of box)"}.get(
                lib.bzamd_slow_instruction_fetch(), "unknown")}
-    if not out["static"] and not out["idle"]:
-        return {"error": "no SMI tool answered"}
+    torch.cuda.synchronize()
+    t0 = time.time()
+    time.sleep(0.5)
+    trace.window("idle", t0, time.time())
     # ~3 s of calls in throughput mode, enqueued ahead of the device (0.1 ms of host per call)
-    calls = 3000
-    for _ in range(calls):
+    calls, skip = 3000, 500
+    begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    for k in range(calls):
+        if k == skip:
+            begin.record()
         lib.bzamd_pipeline_next()
         sequence_call()
-    time.sleep(0.6)  # past the clock ramp
-    out["under_sequence_load"] = smi.sample()
     lib.bzamd_pipeline_flush(stream)
+    end.record()
     torch.cuda.synchronize()
+    t1 = time.time()
+    trace.window("under_sequence_load", t0 + 0.5, t1)  # past the clock ramp
+    out["sequence_leg"] = {"calls": calls, "ms_per_step_last_2500": begin.elapsed_time(end) / (calls - skip)}
     stop = threading.Event()
     count = [0]
 
@@ -636,15 +718,19 @@ def device_state(lib, sequence_call, lone_call, stream):
             count[0] += 1
 
     t = threading.Thread(target=lone_loop)
+    t0 = time.time()
     t.start()
-    time.sleep(0.6)
-    out["under_lone_call_load"] = smi.sample()
+    time.sleep(2.5)
     stop.set()
     t.join()
-    out["under_lone_call_load"]["calls_in_the_leg"] = count[0]
-    out["how"] = (f"amd-smi metric --clock --power --json (GPU 0); sequence leg: {calls} calls of the "
-                  "timed shape enqueued in throughput mode, sampled 0.6 s in; lone leg: calls with a "
-                  "device synchronisation after each, sampled 0.6 s in")
+    t1 = time.time()
+    trace.window("under_lone_call_load", t0 + 0.5, t1)
+    out["lone_leg"] = {"calls": count[0], "ms_per_call_incl_host_sync": 1e3 * (t1 - t0) / max(count[0], 1)}
+    out["how"] = ("amdsmi library (amdsmi_get_gpu_metrics_info) sampled at 50 Hz by tools/prof/"
+                  "smi_trace.py in a process of its own; `energy_counter_mean_w` = the part's energy "
+                  "accumulator over the window's wall time, independent of the sampling; sequence leg: "
+                  f"{calls} calls of the timed shape in throughput mode, the first 0.5 s cut off; lone "
+                  "leg: calls with a device synchronisation after each for 2.5 s, the first 0.5 s cut off")
     return out
 
 
@@ -686,6 +772,49 @@ def host_api():
     return out
 
 
+def box_record(roof, state, legs, lone_call_ms, lib):
+    """`roofline.box` + the same as flat scalars (the driver's record keeps the scalars of `roofline`
+    whole and drops nested objects): which box ran, which kind it is, its clocks and socket power
+    under the sustained leg, the long-run step and the lone call"""
+    tr = state.get("trace", {})
+    seq = tr.get("under_sequence_load", {})
+    lone = tr.get("under_lone_call_load", {})
+    static = dict(tr.get("static", {}))
+    if not static.get("asic_serial"):
+        static.update(state.get("static_cli", {}))
+    fetch = {1: "slow-fetch", 0: "fast-fetch"}.get(lib.bzamd_slow_instruction_fetch(), "unknown")
+    box = {"asic_serial": static.get("asic_serial"),
+           "fetch_kind": fetch,
+           "sclk_mhz_under_sequence": seq.get("sclk_mhz"),
+           "socket_power_w": seq.get("socket_power_w"),
+           "socket_power_w_energy_counter": seq.get("energy_counter_mean_w"),
+           "power_limited_share": seq.get("power_limited_share"),
+           "trace_hz": seq.get("hz"), "trace_samples": seq.get("samples"),
+           "sustained_ms_per_step": state.get("sequence_leg", {}).get("ms_per_step_last_2500"),
+           "sustained_ms_per_step_before_warmup": legs.get("sustained_ms"),
+           "lone_call_ms": lone_call_ms,
+           "lone_leg": {"sclk_mhz": lone.get("sclk_mhz"), "socket_power_w": lone.get("socket_power_w"),
+                        "socket_power_w_energy_counter": lone.get("energy_counter_mean_w")},
+           "idle": tr.get("idle"),
+           "power_cap_w": static.get("power_cap_w")}
+    roof["box"] = box
+    roof["box_asic_serial"] = str(box["asic_serial"])
+    roof["box_fetch_kind"] = fetch
+    roof["box_sustained_ms_per_step"] = box["sustained_ms_per_step"]
+    roof["box_lone_call_ms"] = lone_call_ms
+    if isinstance(seq.get("sclk_mhz"), dict):
+        roof["box_sclk_mhz_under_sequence"] = seq["sclk_mhz"]["mean"]
+    if isinstance(seq.get("socket_power_w"), dict):
+        roof["box_power_w_min"] = seq["socket_power_w"]["min"]
+        roof["box_power_w_mean"] = seq["socket_power_w"]["mean"]
+        roof["box_power_w_max"] = seq["socket_power_w"]["max"]
+    if seq.get("energy_counter_mean_w") is not None:
+        roof["box_power_w_energy_counter"] = seq["energy_counter_mean_w"]
+    if isinstance(lone.get("socket_power_w"), dict):
+        roof["box_power_w_lone_calls_mean"] = lone["socket_power_w"]["mean"]
+    roof["box_trace_hz"] = seq.get("hz")
+
+
 #--------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -723,6 +852,7 @@ def main():
 
     lib = api.load()
     assert api.init(api.SXT_GPU_BACKEND, 0) == 0
+    trace = SmiTrace() if (rank == 0 and world == 1 and not args.no_aux) else None
     # a stream of the bench's own (callers on the NULL stream work too, the engine then uses plain
     # non-blocking tail streams: include/blitzar_amd.h, bzamd_pipeline_next)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -847,6 +977,7 @@ def main():
     # it and the clock -- and the lone-call legs (low load: 40 % of a lone call is tails) after the
     # timed region.
     resident_sequence()
+    IN_RUN_ALU["before"] = probe_alu(lib)
     long_sequence()
 
     for k in range(args.warmup):
@@ -861,6 +992,7 @@ def main():
     # duration); every recorded stage costs an event pair = two stream bubbles per call, so the
     # other five stages are measured by a separate, untimed pass below
     clock = StageClock(lib, args.steps, ACCUMULATE_ONLY)
+    wall0 = time.time()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
@@ -870,7 +1002,10 @@ def main():
         coll.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if trace is not None:
+        trace.window("timed_region", wall0, time.time())
     timed_stages, calls = clock.collect(args.steps)
+    IN_RUN_ALU["after"] = probe_alu(lib)
     all_outputs = outs[:args.steps].cpu().numpy()
     timed_output = all_outputs[-1:].copy()
     assert (all_outputs == timed_output).all(), "the steps of the sequence disagree with each other"
@@ -1002,16 +1137,21 @@ def main():
                                use_pmc=args.log2n is None)
             roof["algorithmic_bytes_per_launch"] = alg_bytes
             roof["kernel_ms"] = per_call["accumulate"]
+            roof["alu_probe"] = {k: v for k, v in IN_RUN_ALU.items() if v}
             result["roofline"] = roof
         if cpu is not None and world == 1:
             result["cpu_baseline"] = cpu
-        if world == 1 and not args.no_configs and args.log2n is None and not args.no_aux:
+        if world == 1 and args.log2n is None and trace is not None:
             try:
-                result["device_state"] = device_state(
+                state = device_state(
                     lib, lambda: lib.bzamd_msm_device(curve_id, vp(outs[0:1]), 1, desc,
                                                       vp(generators), stream),
                     lambda: lib.bzamd_msm_device(curve_id, vp(out), 1, desc, vp(generators), stream),
-                    stream)
+                    stream, trace)
+                state["trace"] = trace.finish()
+                result["device_state"] = state
+                if "roofline" in result:
+                    box_record(result["roofline"], state, legs, single_call_ms, lib)
             except Exception as exc:  # never at the price of the line
                 result["device_state"] = {"error": repr(exc)[:300]}
         if world == 1 and not args.no_configs and args.log2n is None:
@@ -1027,6 +1167,8 @@ def main():
         if dist_info is not None:
             result["distributed"] = dist_info
 
+    if trace is not None and trace.proc is not None and trace.proc.poll() is None:
+        trace.finish()  # (device_state did not run: --log2n)
     api.reset_for_testing()
     if world > 1:
         coll.barrier()

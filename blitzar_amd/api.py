@@ -91,6 +91,8 @@ def load():
     lib.bzamd_kernel_launch_count.restype = ctypes.c_uint64
     lib.bzamd_concurrent_calls_high_water.restype = ctypes.c_uint32
     lib.bzamd_slow_instruction_fetch.restype = ctypes.c_int
+    lib.bzamd_probe_mad_rate.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    lib.bzamd_probe_mad_rate.restype = ctypes.c_int
     lib.bzamd_set_row_pipeline_chunks.argtypes = [u32]
     lib.bzamd_set_row_pipeline_chunks.restype = None
     lib.bzamd_reset_for_testing.restype = None

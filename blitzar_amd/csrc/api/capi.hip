@@ -707,6 +707,12 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
     return;
   }
 
+  // everything below works through devices[0]'s staging, context and gather buffers: the caller
+  // holds that device's lease (lease_all, or lease(primary) for a call in several passes).  The
+  // limits are test knobs re-read here; if one moved between the caller's choice of lease and this
+  // point, stop instead of racing on a device that is not ours.
+  BZ_RELEASE_ASSERT(single == nullptr || single == &st.primary(),
+                    "bzamd_set_max_rows_per_pass / bzamd_set_shard_min_bytes changed during a call");
   if (shard && num_sequences >= num_devices && passes <= 1) {
     const std::vector<unit_range> ranges = split_by_weight(column_weights(cc.cols), num_devices);
     run_on_devices(num_devices, [&](size_t k) {
@@ -802,6 +808,7 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
   // which devices the call needs is a function of its shapes alone
   const checked_columns cc = check_descriptors(descriptors, num_sequences);
   const bool several_passes = cc.longest > g_max_rows_per_pass.load();
+  const current_device_guard restore_callers_device; // the call may run on any device (lease_any)
   if (shards_over_devices(st, cc)) {
     api_state::device_lease lease = st.lease_all();
     compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
@@ -1006,6 +1013,7 @@ void handle_make_resident(multiexp_handle& h) {
   api_state& st = state();
   if (st.backend != SXT_GPU_BACKEND || h.n == 0) return;
   const size_t bytes = h.vt->projective_size * h.n;
+  const current_device_guard restore_callers_device;
   for (auto& dsp : st.devices) {
     device_state& ds = *dsp;
     const api_state::device_lease lease = st.lease(ds);
@@ -1020,7 +1028,6 @@ void handle_make_resident(multiexp_handle& h) {
     h.tables.push_back(table);
     h.devices.push_back(ds.device);
   }
-  st.primary().activate();
 }
 
 // the three fixed-base entry points differ only in how a row is cut into per-output bit fields
@@ -1157,9 +1164,14 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   std::vector<unit_range> ranges{{0, num_outputs}};
   if (shard) ranges = split_by_weight(column_weights(cols), num_devices);
   u8* out = static_cast<u8*>(res);
-  // GPU backend: every device for a sharded call, else the first one nobody holds
+  // GPU backend: every device for a sharded call, else the first one nobody holds; the calling
+  // thread gets its own current device back when the call returns
   api_state::device_lease lease;
-  if (st.backend == SXT_GPU_BACKEND) lease = shard ? st.lease_all() : st.lease_any();
+  std::unique_ptr<current_device_guard> restore_callers_device;
+  if (st.backend == SXT_GPU_BACKEND) {
+    restore_callers_device = std::make_unique<current_device_guard>();
+    lease = shard ? st.lease_all() : st.lease_any();
+  }
 
   if (st.backend == SXT_CPU_BACKEND) {
     run_on_devices(ranges.size(), [&](size_t k) {
@@ -1212,7 +1224,6 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
                                 hipMemcpyDeviceToHost, ds.stream));
     BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
   });
-  st.primary().activate();
   record_result();
 }
 } // namespace
@@ -1452,6 +1463,12 @@ int bzamd_accumulate_form(void) {
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
 
+int bzamd_probe_mad_rate(double target_ms, double* out) {
+  api_state& st = state();
+  if (st.backend != SXT_GPU_BACKEND || out == nullptr) return -1;
+  return msm_probe_mad_rate(target_ms, out) ? 0 : -1;
+}
+
 int bzamd_slow_instruction_fetch(void) {
   if (g_state == nullptr || g_state->backend != SXT_GPU_BACKEND) return -1;
   return msm_context_slow_instruction_fetch(g_state->context_for_current_device()) ? 1 : 0;
@@ -1666,6 +1683,7 @@ void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_
         std::mutex mu;
         std::condition_variable cv;
         bool done = false;
+        bool abandoned = false; // the deadline passed: whoever finishes the init cleans up after it
         ncclResult_t result = ncclSuccess;
       };
       auto job = std::make_shared<init_job>();
@@ -1675,10 +1693,18 @@ void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_
       std::thread([job, rccl] {
         const ncclResult_t r =
             rccl->comm_init_all(job->comms.data(), static_cast<int>(job->ids.size()), job->ids.data());
-        std::lock_guard<std::mutex> lock(job->mu);
-        job->result = r;
-        job->done = true;
-        job->cv.notify_all();
+        bool late = false;
+        {
+          std::lock_guard<std::mutex> lock(job->mu);
+          job->result = r;
+          job->done = true;
+          late = job->abandoned;
+          job->cv.notify_all();
+        }
+        // finished after the deadline: nobody will ever use (or destroy) these communicators
+        if (late && r == ncclSuccess) {
+          for (ncclComm_t c : job->comms) (void)rccl->comm_destroy(c);
+        }
       }).detach();
       long deadline_s = 60;
       if (const char* v = std::getenv("BLITZAR_AMD_RCCL_INIT_TIMEOUT_S")) {
@@ -1695,6 +1721,9 @@ void bzamd_msm_multi_device(unsigned curve_id, void* const* commitments, uint32_
         };
         st.exchange_state = 1;
       } else if (!in_time) {
+        // (a hung init leaves its helper thread behind, inside RCCL; if it does return, the thread
+        // destroys what it created)
+        job->abandoned = true;
         std::fprintf(stderr, "blitzar_amd: ncclCommInitAll did not return within %ld s; using peer "
                              "copies\n", deadline_s);
       } else {

@@ -92,6 +92,24 @@ struct resident_table {
   }
 };
 
+// A blocking call may run on any device of the backend (per-device leases) and activates it on the
+// calling thread; the thread's own current device -- what its later allocations and bzamd_*_device
+// calls resolve against -- is put back when the call returns.
+struct current_device_guard {
+  int saved = -1;
+  current_device_guard() {
+    if (hipGetDevice(&saved) != hipSuccess) {
+      (void)hipGetLastError();
+      saved = -1;
+    }
+  }
+  ~current_device_guard() {
+    if (saved >= 0) (void)hipSetDevice(saved);
+  }
+  current_device_guard(const current_device_guard&) = delete;
+  current_device_guard& operator=(const current_device_guard&) = delete;
+};
+
 struct device_state {
   // A blocking sxt_* call owns the devices it runs on for its duration: their stream pair, engine
   // context and staging arena (api_state::device_lease).  Calls on different devices run

@@ -76,7 +76,81 @@ bool probe_slow_instruction_fetch() {
   g_kernel_launches += 6;
   return small > 0 && large > 1.4 * small;
 }
+
+// Issue rate of v_mad_u64_u32 on THIS device, now: every SIMD holds 8 waves, each runs 8 independent
+// chains of the instruction (the field products' one wide primitive).  A launch lasts ~4 ms; launches
+// repeat until `target_ms` of load have passed, and the LAST launch is the one measured (the part
+// clocks to its power budget under this load, not to the nominal 2.4 GHz).
+constexpr int kMadProbeIters = 8192, kMadProbeChains = 8;
+__global__ void __launch_bounds__(256) k_probe_mad(u64* out, u64* ticks, u32 seed) {
+  u64 a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 9, a5 = a0 * 11,
+      a6 = a0 * 13, a7 = a0 * 15;
+  const u32 x = seed * 2654435761u + threadIdx.x, y = x ^ 0x9e3779b9u;
+#define BZ_PROBE_MAD(v) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(v) : "v"(x), "v"(y) : "vcc");
+  const u64 t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kMadProbeIters; ++it) {
+    BZ_PROBE_MAD(a0) BZ_PROBE_MAD(a1) BZ_PROBE_MAD(a2) BZ_PROBE_MAD(a3)
+    BZ_PROBE_MAD(a4) BZ_PROBE_MAD(a5) BZ_PROBE_MAD(a6) BZ_PROBE_MAD(a7)
+  }
+  const u64 t1 = __builtin_amdgcn_s_memtime();
+#undef BZ_PROBE_MAD
+  out[static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+  if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
 } // namespace
+
+// out[0] wave-instructions per second over the whole device, out[1] effective shader clock (Hz:
+// s_memtime ticks of the longest wave / wall time of its launch), out[2] shader cycles per
+// wave-instruction and SIMD, out[3] milliseconds of load the probe ran
+bool msm_probe_mad_rate(double target_ms, double out[4]) {
+  int device = 0, cus = 0;
+  BZ_HIP_CHECK(hipGetDevice(&device));
+  BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  const u32 blocks = static_cast<u32>(cus) * 8; // 4 SIMDs per CU, 4 waves per block: 8 waves per SIMD
+  u64 *d_out = nullptr, *d_ticks = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(u64) * 256 * blocks) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_ticks), sizeof(u64) * blocks) != hipSuccess) {
+    (void)hipGetLastError();
+    if (d_out != nullptr) (void)hipFree(d_out);
+    return false;
+  }
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, first = nullptr;
+  BZ_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  BZ_HIP_CHECK(hipEventCreate(&e0));
+  BZ_HIP_CHECK(hipEventCreate(&e1));
+  BZ_HIP_CHECK(hipEventCreate(&first));
+  BZ_HIP_CHECK(hipEventRecord(first, stream));
+  float total_ms = 0, last_ms = 0;
+  u32 launches = 0;
+  do {
+    BZ_HIP_CHECK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_probe_mad, dim3(blocks), dim3(256), 0, stream, d_out, d_ticks, 1u + launches);
+    BZ_HIP_CHECK(hipEventRecord(e1, stream));
+    BZ_HIP_CHECK(hipEventSynchronize(e1));
+    BZ_HIP_CHECK(hipEventElapsedTime(&last_ms, e0, e1));
+    BZ_HIP_CHECK(hipEventElapsedTime(&total_ms, first, e1));
+    launches += 1;
+  } while (total_ms < target_ms && launches < 4096);
+  std::vector<u64> ticks(blocks);
+  BZ_HIP_CHECK(hipMemcpy(ticks.data(), d_ticks, sizeof(u64) * blocks, hipMemcpyDeviceToHost));
+  u64 longest = 0;
+  for (u64 t : ticks) longest = t > longest ? t : longest;
+  const double instructions_per_wave = static_cast<double>(kMadProbeIters) * kMadProbeChains;
+  const double waves = static_cast<double>(blocks) * 4;
+  out[0] = instructions_per_wave * waves / (static_cast<double>(last_ms) * 1e-3);
+  out[1] = static_cast<double>(longest) / (static_cast<double>(last_ms) * 1e-3);
+  out[2] = static_cast<double>(longest) / (instructions_per_wave * 8);
+  out[3] = total_ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(first);
+  (void)hipStreamDestroy(stream);
+  (void)hipFree(d_out);
+  (void)hipFree(d_ticks);
+  g_kernel_launches += launches;
+  return last_ms > 0;
+}
 
 msm_context* msm_context_new() {
   auto* ctx = new msm_context();

@@ -86,6 +86,8 @@ const curve_vtable* curve_vtable_for(unsigned curve_id);
 msm_context* msm_context_new();
 // what the context's device answered to the instruction-fetch probe at creation (context.hip)
 bool msm_context_slow_instruction_fetch(msm_context* ctx);
+// measured issue rate of v_mad_u64_u32 on the current device under an all-SIMD load (context.hip)
+bool msm_probe_mad_rate(double target_ms, double out[4]);
 void msm_context_free(msm_context* ctx);
 // engine knobs (0 keeps the current value): window width cap (2..16), tasks and workspace bytes
 // per batch of columns

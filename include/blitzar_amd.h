@@ -71,6 +71,15 @@ uint32_t bzamd_concurrent_calls_high_water(void);
  * (probed once per device; such devices run the bucket reduction of calls with few columns through
  * k_reduce_compact), 0 if not, -1 without an initialised GPU backend */
 int bzamd_slow_instruction_fetch(void);
+/* Issue rate of v_mad_u64_u32 -- the field products' one wide primitive, the binding bound of the
+ * bucket accumulation -- on the current device, measured now: every SIMD holds 8 waves of 8
+ * independent chains for about `target_ms` milliseconds, the last ~4 ms launch is what is reported.
+ *   out[0] wave-instructions per second over the whole device
+ *   out[1] effective shader clock in Hz (s_memtime ticks of the longest wave / wall time)
+ *   out[2] shader cycles per wave-instruction and SIMD
+ *   out[3] milliseconds of load the probe ran
+ * Returns 0, or -1 without the GPU backend.  bench.py normalises `roofline.alu` with it. */
+int bzamd_probe_mad_rate(double target_ms, double* out);
 /* drop the backend singleton so that sxt_init may be called again (reference:
  * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
 void bzamd_reset_for_testing(void);

@@ -1,0 +1,69 @@
+#!/bin/bash
+# One GPU session on a gpurun box, as a list of steps (replaces the per-session scripts of rounds 3-4):
+#   gpurun --timeout 1500 -- 'bash tools/prof/gpu_session.sh <tag> step [step ...]'
+# Everything is written under gpurun_out/<tag>/ (merged back by gpurun).  Steps:
+#   info        which box: amd-smi static, rocm-smi clocks / power / partitions
+#   tests       python -m pytest tests -m gpu -x -q
+#   tests:<k>   the same with -k <k>
+#   bench       python bench.py (the driver's default line)            -> bench.json
+#   bench-quick python bench.py --no-configs --skip-headline-check     -> bench_quick.json
+#   stats       rocprofv3 --kernel-trace --stats of bench.py --no-aux  -> prof_stats/
+#   pmc         three --pmc passes (SQ_*, FETCH_SIZE, WRITE_SIZE) of bench.py --no-aux, no tracing
+#   ab:<spec-file>   tools/prof/ab_pipeline.sh over the lines of <spec-file> ("<bench args> -- <specs>")
+#   grid        the reference's benchmark grid + the short-column / many-column regime -> grid.json
+#   cmd:<file>  bash <file> (a one-off, kept under gpurun_out/)
+cd "${GRAFT_REPO_ROOT:-.}" || exit 1
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+for step in "$@"; do
+  echo "==== $step $(date +%T)" | tee -a "$OUT/session.log"
+  case "$step" in
+    info)
+      (amd-smi static --asic --vbios --json; rocm-smi --showclocks --showpower --showcomputepartition \
+        --showmemorypartition --showperflevel; nproc) > "$OUT/info.txt" 2>&1 ;;
+    tests)
+      timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/gputests.log" 2>&1
+      tail -3 "$OUT/gputests.log" | tee -a "$OUT/session.log" ;;
+    tests:*)
+      timeout 900 python -m pytest tests -m gpu -x -q -k "${step#tests:}" > "$OUT/gputests_k.log" 2>&1
+      tail -3 "$OUT/gputests_k.log" | tee -a "$OUT/session.log" ;;
+    bench)
+      timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+      echo "rc=$? $(wc -c < "$OUT/bench.json") bytes" | tee -a "$OUT/session.log" ;;
+    bench-quick)
+      timeout 600 python bench.py --no-configs --skip-headline-check > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
+      echo "rc=$?" | tee -a "$OUT/session.log" ;;
+    stats)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_stats" -- \
+        python "$OLDPWD/bench.py" --no-aux --skip-headline-check > "$OLDPWD/$OUT/stats_bench.json" 2> "$OLDPWD/$OUT/stats.err")
+      find "$OUT/prof_stats" -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+      echo "rc=$?" | tee -a "$OUT/session.log" ;;
+    pmc)
+      for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
+                 "FETCH_SIZE" "WRITE_SIZE"; do
+        name=$(echo $set | cut -d' ' -f1)
+        (cd /tmp && timeout 900 rocprofv3 --pmc $set -d "$OLDPWD/$OUT/pmc_$name" -- \
+          python "$OLDPWD/bench.py" --no-aux --skip-headline-check --steps 5 --config-steps 1 \
+          > "$OLDPWD/$OUT/pmc_$name.json" 2> "$OLDPWD/$OUT/pmc_$name.err")
+        echo "pmc $name rc=$?" | tee -a "$OUT/session.log"
+      done ;;
+    ab:*)
+      while IFS= read -r line; do
+        [ -z "$line" ] && continue
+        case "$line" in \#*) continue;; esac
+        # shellcheck disable=SC2086
+        bash tools/prof/ab_pipeline.sh "$OUT/ab.log" $line
+      done < "${step#ab:}"
+      tail -40 "$OUT/ab.log" ;;
+    grid)
+      timeout 1200 python tools/grid_bench.py --out "$OUT/grid.json" > "$OUT/grid.log" 2>&1
+      echo "rc=$?" | tee -a "$OUT/session.log"; tail -5 "$OUT/grid.log" ;;
+    cmd:*)
+      bash "${step#cmd:}" > "$OUT/cmd_$(basename "${step#cmd:}").log" 2>&1
+      echo "rc=$?" | tee -a "$OUT/session.log" ;;
+    *) echo "unknown step $step" | tee -a "$OUT/session.log" ;;
+  esac
+done
+echo "==== done $(date +%T)" | tee -a "$OUT/session.log"
