@@ -38,6 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from blitzar_amd import api  # noqa: E402
 import baseline_workloads as wl  # noqa: E402
 
+START_WALL = time.time()
 STAGES = ["prepare_addends", "recode", "bucket_sort", "accumulate", "reduce", "combine"]
 ACC_KERNEL = {0: "k_accumulate<bz::ed25519_msm>", 1: "k_accumulate<bz::bls12_381_msm>",
               2: "k_accumulate<bz::bn254_msm>", 3: "k_accumulate<bz::grumpkin_msm>"}
@@ -68,6 +69,9 @@ def parse_args():
                     help="profiling runs: keep the oracle for the configs legs but skip the 16 s "
                          "reference-CPU run on the headline column (no `verified`, no cpu_baseline)")
     ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--config4-log2n", type=int, default=20,
+                    help="rows of the sharded config-4 leg under --gpus N (debug / dry runs only: the "
+                         "config is 2^20 rows)")
     ap.add_argument("--no-aux", action="store_true",
                     help="profiling runs: skip the device_state legs (3000 extra calls) and the "
                          "host_api child processes")
@@ -561,7 +565,7 @@ def strong_scaling_config2(lib, args, dev, stream, rank, world, dist, coll, gene
 def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll):
     """N > 1: config 4's 256 columns sharded over the ranks (strong scaling), one all-gather of
     the 72-byte commitments"""
-    cid, n, columns = 2, 1 << 20, 256
+    cid, n, columns = 2, 1 << args.config4_log2n, 256
     per = columns // world
     begin = rank * per
     # this rank's columns of the ONE mt19937{0} stream of the config (jump-ahead to column `begin`)
@@ -602,7 +606,7 @@ def sharded_config4(lib, oracle, args, dev, stream, rank, world, dist, coll):
     coll.all_reduce(flag, dist.ReduceOp.MIN)
     assert int(flag.item()) == 1, "sharded config 4: a commitment differs from the reference"
     ops = world * per * n
-    return {"config": f"4: bn254 G1, {world * per} columns x 2^20 rows sharded over {world} GPUs "
+    return {"config": f"4: bn254 G1, {world * per} columns x 2^{args.config4_log2n} rows sharded over {world} GPUs "
                       "(RCCL all-gather of the commitments)", "scaling": "strong",
             "columns_per_gpu": per, "ms_per_call": dt * 1e3, "scalar_point_ops_per_s": ops / dt,
             "commitments_per_s": world * per / dt,
@@ -1166,6 +1170,10 @@ def main():
             result["strong_scaling_config2"] = strong2
         if dist_info is not None:
             result["distributed"] = dist_info
+        if args.dry_run_one_gpu:
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            result["dry_run"] = {"ranks_on_one_gpu": world, "device_bytes_in_use": int(total_b - free_b),
+                                 "wall_s_since_start": time.time() - START_WALL}
 
     if trace is not None and trace.proc is not None and trace.proc.poll() is None:
         trace.finish()  # (device_state did not run: --log2n)

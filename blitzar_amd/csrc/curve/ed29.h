@@ -32,20 +32,14 @@ struct alignas(16) ed29_niels {
 static_assert(sizeof(ed29_niels) == 128);
 
 // ed29_cached as it sits in HBM: the four coordinates as canonical 256-bit little-endian integers,
-// 128 bytes = exactly one line per gather (144 bytes of limbs straddle 3-4 sectors of 64 bytes;
-// measured: the aligned form is worth more than the ~70 VALU instructions that unpack it)
+// 128 bytes = exactly one line per gather.  (144-byte limb rows need nothing unpacked -- 1250 -> 1211
+// VALU instructions per addition -- but are two line requests per gather: measured in round 5,
+// k_accumulate 0.636 -> 0.940 ms at 2^20 rows, profiles/round5_ab_limb_addends.log.)
 struct alignas(16) ed29_cached_packed {
   u32 w[32];
 };
 static_assert(sizeof(ed29_cached_packed) == 128);
 
-// A/B variant (BZ_ED_LIMB_ADDENDS): the four coordinates as their nine 29-bit limbs, 144 bytes per
-// row -- nothing to unpack (44 v_alignbit + 36 masks per addition) at the price of rows that straddle
-// three or four 64-byte sectors instead of two
-struct alignas(16) ed29_cached_limbs {
-  u32 w[36];
-};
-static_assert(sizeof(ed29_cached_limbs) == 144);
 namespace ed29 {
 BZ_HD void pack_words(u32* w, const fe29& f) {
   u64 q[4];
@@ -115,48 +109,6 @@ BZ_HD ed29_cached_packed gather_signed(const ed29_cached_packed* table, u32 row,
   dst[3] = src[3 - a];
 #pragma unroll
   for (int i = 4; i < 8; ++i) dst[i] = src[i];
-  return q;
-}
-
-BZ_HD ed29_cached_limbs pack_limbs(const ed29_cached& c) {
-  ed29_cached_limbs m;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    m.w[i] = c.YpX.v[i];
-    m.w[9 + i] = c.YmX.v[i];
-    m.w[18 + i] = c.Z.v[i];
-    m.w[27 + i] = c.T2d.v[i];
-  }
-  return m;
-}
-BZ_HD ed29_cached unpack(const ed29_cached_limbs& m) {
-  ed29_cached c;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    c.YpX.v[i] = m.w[i];
-    c.YmX.v[i] = m.w[9 + i];
-    c.Z.v[i] = m.w[18 + i];
-    c.T2d.v[i] = m.w[27 + i];
-  }
-  return c;
-}
-// the (Y+X | Y-X) pieces exchanged by address when `negate`
-BZ_HD ed29_cached_limbs gather_signed(const ed29_cached_limbs* table, u32 row, bool negate) {
-  const u32* src = table[row].w;
-  const u32 a = negate ? 9u : 0u;
-  ed29_cached_limbs q;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    q.w[i] = src[a + i];
-    q.w[9 + i] = src[9 - a + i];
-  }
-  const u32x4* rest = reinterpret_cast<const u32x4*>(src + 16);
-  // words 18..35 (Z | 2dT): 8-byte aligned, read as 16-byte vectors from word 16 on
-  u32x4 v[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) v[i] = rest[i];
-#pragma unroll
-  for (int i = 18; i < 36; ++i) q.w[i] = v[(i - 16) / 4].v[(i - 16) % 4];
   return q;
 }
 

@@ -33,14 +33,7 @@ static_assert(sizeof(sw_api_affine<6>) == 104);
 struct ed25519_msm {
   static constexpr unsigned curve_id = 0;
   using point = ed29_point;
-#ifndef BZ_ED_LIMB_ADDENDS
-#define BZ_ED_LIMB_ADDENDS 0
-#endif
-#if BZ_ED_LIMB_ADDENDS
-  using addend = ed29_cached_limbs;  // (Y+X, Y-X, Z, 2dT), 4 x 9 limbs (A/B variant)
-#else
   using addend = ed29_cached_packed; // (Y+X, Y-X, Z, 2dT), 4 x 256 bits
-#endif
   using api_projective = ed_point; // sxt_ristretto255 / c21t::element_p3
   // Itanium-mangled names of the reference types (meta.txt of a BLITZAR_DUMP_DIR recording)
   static constexpr const char* reference_element_name = "N3sxt4c21t10element_p3E";
@@ -87,11 +80,7 @@ struct ed25519_msm {
     acc = ed29::add_cached_presigned(acc, q, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
-#if BZ_ED_LIMB_ADDENDS
-    return ed29::pack_limbs(ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]));
-#else
     return ed29::pack(ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]));
-#endif
   }
   // handle generators arrive as element_p3 too
   BZ_HD static addend addend_from_api_projective(const void* projective, u64 i) {

@@ -1,7 +1,9 @@
-"""bench.py's N > 1 control flow on a one-GPU box (-m gpu): two ranks, both on cuda:0, collectives
+"""bench.py's N > 1 control flow on a one-GPU box (-m gpu): N ranks, all on cuda:0, collectives
 through gloo on host copies (--dry-run-one-gpu; never a measurement).  Checks that the line carries
 the weak-scaling value, the row-split strong-scaling leg of the headline column (whose commitments
-must equal rank 0's commitment of the whole column) and the distributed block."""
+must equal rank 0's commitment of the whole column), the distributed block, and -- with the oracle --
+the verified headline commitment of every rank and config 4's 256 columns sharded over the ranks
+(at reduced rows: --log2n / --config4-log2n), inside a wall-clock and a device-memory budget."""
 import json
 import os
 import subprocess
@@ -28,3 +30,43 @@ def test_two_ranks_dry_run():
     assert strong["scaling"] == "strong" and strong["rows_per_gpu"] == 1 << 19
     assert strong["ms_per_step"] > 0 and "verified" in strong
     assert d["distributed"]["rccl_world_size"] == 2
+
+
+def _dry_run(ranks, port, extra, timeout):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(ranks), "--dry-run-one-gpu"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_two_ranks_dry_run_with_oracle_and_sharded_config4(oracle):
+    """the legs the plain dry run drops: every rank verifies its timed commitment against the
+    reference CPU backend, and config 4's 256 columns are sharded 128 / 128 with one all-gather, every
+    rank checking its shard inside the gathered buffer (2^14 / 2^12 rows: seconds of oracle)"""
+    d = _dry_run(2, 29619, ["--steps", "3", "--warmup", "1", "--log2n", "14", "--config4-log2n", "12",
+                            "--config-steps", "2"], 900)
+    assert d["n_gpus"] == 2 and "verified" in d
+    sharded = d["strong_scaling"]
+    assert sharded["columns_per_gpu"] == 128 and sharded["ms_per_call"] > 0
+    assert "bit-exact" in sharded["verified"]
+    assert d["strong_scaling_config2"]["rows_per_gpu"] == 1 << 13
+    assert d["distributed"]["rccl_world_size"] == 2
+
+
+@pytest.mark.gpu
+def test_eight_ranks_dry_run_inside_budget(oracle):
+    """first contact with --gpus 8 on what one GPU can show: 8 processes, 8 HIP contexts and engine
+    workspaces on cuda:0, the rendezvous, the three collectives of the line at world size 8, config 4
+    sharded 32 columns per rank -- inside 16 GiB of device memory and ten minutes of wall clock"""
+    d = _dry_run(8, 29621, ["--steps", "2", "--warmup", "1", "--log2n", "12", "--config4-log2n", "10",
+                            "--config-steps", "1"], 600)
+    assert d["n_gpus"] == 8 and d["distributed"]["rccl_world_size"] == 8
+    assert d["strong_scaling"]["columns_per_gpu"] == 32
+    assert d["strong_scaling_config2"]["rows_per_gpu"] == 1 << 9
+    assert d["dry_run"]["ranks_on_one_gpu"] == 8
+    assert d["dry_run"]["device_bytes_in_use"] < 16 << 30, d["dry_run"]
+    assert d["dry_run"]["wall_s_since_start"] < 600
