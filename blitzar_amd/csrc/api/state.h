@@ -31,10 +31,17 @@ namespace bz {
 
 // A resident generator set on one device: slice 0 = the set's addends; when window tables are on
 // (sets of at least kWindowTableMinGenerators generators, BLITZAR_AMD_WINDOW_TABLES != 0) the
-// 2^(16 w) multiples follow, `stride` rows apart -- 17 x the memory (2.2 GB for 2^20 curve25519
-// generators) buys one bucket reduction per column instead of one per window and no Horner chain.
+// 2^(bits w) multiples follow, `stride` rows apart -- 17 x the memory at bits = 16 (2.2 GB for 2^20
+// curve25519 generators), 15 x at bits = 18 -- which buys one bucket reduction per column instead of
+// one per window and no Horner chain.
+// Window width of the table: with ONE bucket set per column, 2^17 buckets are affordable where W
+// separate sets were not, so sets of 2^18 generators or more take bits = 18 (256-bit columns: 15
+// windows instead of 17; by the planner's cost model W n + 3.5 x 2^(bits - 1) that is 15.4 n against
+// 17.1 n at n = 2^20, 16.75 n against 17.4 n at 2^18, and 22 n against 18.75 n at 2^16, which
+// therefore stays at 16).  BLITZAR_AMD_WINDOW_TABLE_BITS (16 .. 20) overrides (tests, A/B runs).
 constexpr u64 kWindowTableMinGenerators = u64{1} << 14;
-constexpr u32 kWindowTableSlices = 17; // 256-bit scalars + the signed-digit carry, 16-bit windows
+constexpr u64 kWideWindowTableMinGenerators = u64{1} << 18;
+inline u32 window_table_slices(u32 bits) { return (256 + 1 + bits - 1) / bits; } // + the carry
 struct resident_table {
   void* d_addends = nullptr;
   u64 n = 0;
@@ -56,7 +63,14 @@ struct resident_table {
     if (const char* v = std::getenv("BLITZAR_AMD_WINDOW_TABLE_MIN")) {
       least = std::strtoull(v, nullptr, 10); // tests: tables for small sets too
     }
-    u32 windows = wanted && count >= least ? kWindowTableSlices : 1;
+    u32 bits = count >= kWideWindowTableMinGenerators ? 18 : 16;
+    if (const char* v = std::getenv("BLITZAR_AMD_WINDOW_TABLE_BITS")) {
+      const unsigned long b = std::strtoul(v, nullptr, 10);
+      BZ_RELEASE_ASSERT(b >= 16 && b <= kMaxTableWindowBits,
+                        "BLITZAR_AMD_WINDOW_TABLE_BITS must be in [16, 20]");
+      bits = static_cast<u32>(b);
+    }
+    u32 windows = wanted && count >= least ? window_table_slices(bits) : 1;
     const u64 stride = (count + 7) & ~u64{7};
     const size_t row = vt.resident_addend_size;
     if (windows > 1) {
@@ -79,11 +93,12 @@ struct resident_table {
       err = hipMalloc(&d_addends, row * (stride + 1));
     }
     BZ_HIP_CHECK(err);
-    vt.build_window_table(d_addends, d_source, source_projective, count, stride, windows, stream);
+    vt.build_window_table(d_addends, d_source, source_projective, count, stride, windows, bits,
+                          stream);
     if (windows > 1) {
       shape.stride = stride;
       shape.windows = windows;
-      shape.bits = 16;
+      shape.bits = bits;
     }
   }
   void release() {

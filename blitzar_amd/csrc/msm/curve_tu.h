@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(64)
 }
 
 //--------------------------------------------------------------------------------------------------
-// window tables of resident generator sets (plan.h: window_table): slice w = 2^(16 w) g_i as
-// addends, built by a chain of 16 doublings per slice on engine points and one shared-inversion
+// window tables of resident generator sets (plan.h: window_table): slice w = 2^(bits w) g_i as
+// addends, built by a chain of `bits` doublings per slice on engine points and one shared-inversion
 // normalisation per slice
 //--------------------------------------------------------------------------------------------------
 template <class R>
@@ -133,10 +133,10 @@ template <class C, class R = C, class H = C> struct curve_tu {
     msm_enqueue<R>(ctx, d_out, out_stride, projective_out, cols,
                    static_cast<const typename R::addend*>(d_addends), nullptr, stream, tables);
   }
-  // slices 0 .. windows-1 of a resident set: d_table[w * stride + i] = addend of 2^(16 w) g_i
+  // slices 0 .. windows-1 of a resident set: d_table[w * stride + i] = addend of 2^(bits w) g_i
   // (blocking: scratch for the chain of points is allocated and freed here)
   static void build_window_table(void* d_table, const void* d_source, bool source_projective,
-                                 u64 n, u64 stride, u32 windows, hipStream_t stream) {
+                                 u64 n, u64 stride, u32 windows, u32 bits, hipStream_t stream) {
     if (n == 0) return;
     using point = typename R::point;
     point* d_points = nullptr;
@@ -148,7 +148,7 @@ template <class C, class R = C, class H = C> struct curve_tu {
     for (u32 w = 0; w < windows; ++w) {
       if (w != 0) {
         hipLaunchKernelGGL((k_double_points<R>), dim3(blocks), dim3(256), 0, stream, d_points, n,
-                           16);
+                           static_cast<int>(bits));
       }
       hipLaunchKernelGGL((k_points_to_addends<R>),
                          dim3(ceil_div_u32(n, 256ull * R::batch_points_per_lane)), dim3(256), 0,

@@ -57,10 +57,10 @@ struct curve_vtable {
                            hipStream_t stream);
   void (*prepare_resident_projective)(void* d_addends, const void* d_projective, u64 n,
                                       hipStream_t stream);
-  // window table of a resident set: d_table[w * stride + i] = addend of 2^(16 w) g_i for
+  // window table of a resident set: d_table[w * stride + i] = addend of 2^(bits w) g_i for
   // w < windows, from C-ABI generators or projective elements on the device (blocking)
   void (*build_window_table)(void* d_table, const void* d_source, bool source_projective, u64 n,
-                             u64 stride, u32 windows, hipStream_t stream);
+                             u64 stride, u32 windows, u32 bits, hipStream_t stream);
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
   bool (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);

@@ -285,14 +285,18 @@ struct msm_context {
 // context's mutex held and the context's device current.
 static void configure_sort_kernels(msm_context& ctx) {
   if (ctx.kernels_configured) return;
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_recode_packed),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_hist),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-  BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_scatter<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  auto allow_lds = [](auto kernel) {
+    BZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  };
+  allow_lds(k_recode_packed<i16>);
+  allow_lds(k_recode_packed<i32>);
+  allow_lds(k_group_hist<i16>);
+  allow_lds(k_group_hist<i32>);
+  allow_lds(k_group_scatter<true, i16>);
+  allow_lds(k_group_scatter<true, i32>);
+  allow_lds(k_group_scatter<false, i16>);
+  allow_lds(k_group_scatter<false, i32>);
   ctx.kernels_configured = true;
 }
 
@@ -322,7 +326,7 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   // what the front writes and the accumulation reads
   size_t front = 0;
   if (needs_addends) front += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
-  front += device_arena::padded(sizeof(i16) * (plan.total_entries + 8));
+  front += device_arena::padded((plan.wide_digits ? sizeof(i32) : sizeof(i16)) * (plan.total_entries + 8));
   front += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
   front += 2 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
   front += device_arena::padded(sizeof(u32) * zeroed_block_words(plan.total_groups, num_tasks));
@@ -445,7 +449,7 @@ template <class C> struct batch_buffers {
   column_desc* cols;
   task_desc* tasks;
   const typename C::addend* addends;
-  i16* digits;
+  void* digits; // i16 [total_entries], or i32 when plan.wide_digits
   u32* records;
   u32* sorted;
   u32* group_cursor;
@@ -505,7 +509,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                 static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
                 static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
                 static_cast<u64>(d_addends == nullptr),
-                static_cast<u64>(mode.piped)}) {
+                static_cast<u64>(mode.piped) | static_cast<u64>(plan.wide_digits) << 1}) {
     layout = (layout ^ v) * 0x100000001b3ull;
   }
   if (ctx.any_pending() && layout != ctx.pipe_layout) ctx.join_all(stream);
@@ -565,7 +569,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // carve the arena: the same walk for every batch of a layout, this batch's sets picked out
   {
     addend* prepared = d_addends == nullptr ? ctx.arena.take<addend>(plan.max_rows + 1) : nullptr;
-    i16* digits = ctx.arena.take<i16>(plan.total_entries + 8);
+    void* digits = plan.wide_digits ? static_cast<void*>(ctx.arena.take<i32>(plan.total_entries + 8))
+                                    : static_cast<void*>(ctx.arena.take<i16>(plan.total_entries + 8));
     u32* records = ctx.arena.take<u32>(plan.total_entries + 8);
     u32* sorted = ctx.arena.take<u32>(plan.total_entries + 8);
     u32* group_cursor = ctx.arena.take<u32>(zeroed_block_words(plan.total_groups, num_tasks));
@@ -637,46 +642,61 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                                c.num_windows == 17 &&
                                (reinterpret_cast<uintptr_t>(c.data) & 15) == 0));
   }
-  ctx.timer.timed(timing, 1, fs, [&] {
-    if (d_ranges != nullptr) {
-      hipLaunchKernelGGL(k_recode_packed,
-                         dim3(ceil_div_u32(plan.max_recode_rows, kPackedTileRows)),
-                         dim3(kPackedRecodeThreads), kPackedTileBytes, fs, b.digits, b.cols,
-                         b.tasks, d_ranges, static_cast<u32>(ranges.size()),
-                         plan.columns[0].row_stride, plan.max_recode_rows, plan.max_rows,
-                         b.group_cursor, zero_words);
-      return;
-    }
-    const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
-    if (rows32_c16) {
-      hipLaunchKernelGGL(k_recode_rows32_c16, dim3(chunks, num_cols), dim3(256), 0, fs, b.digits,
-                         b.cols, b.tasks, b.group_cursor, zero_words);
-      return;
-    }
-    const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
-    const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
-    hipLaunchKernelGGL(k_recode, dim3(recode_blocks), dim3(256), 0, fs, b.digits, b.cols,
-                       b.tasks, num_cols, chunks, b.group_cursor, zero_words);
-  });
+  // the kernels that write / read the stored digits, for the launch's digit type
+  auto recode_and_partition = [&](auto digit_tag) {
+    using D = decltype(digit_tag);
+    D* digits = static_cast<D*>(b.digits);
+    ctx.timer.timed(timing, 1, fs, [&] {
+      if (d_ranges != nullptr) {
+        hipLaunchKernelGGL((k_recode_packed<D>),
+                           dim3(ceil_div_u32(plan.max_recode_rows, kPackedTileRows)),
+                           dim3(kPackedRecodeThreads), kPackedTileBytes, fs, digits, b.cols,
+                           b.tasks, d_ranges, static_cast<u32>(ranges.size()),
+                           plan.columns[0].row_stride, plan.max_recode_rows, plan.max_rows,
+                           b.group_cursor, zero_words);
+        return;
+      }
+      const u32 chunks = ceil_div_u32(plan.max_recode_rows, 256);
+      if constexpr (sizeof(D) == 2) {
+        if (rows32_c16) {
+          hipLaunchKernelGGL(k_recode_rows32_c16, dim3(chunks, num_cols), dim3(256), 0, fs, digits,
+                             b.cols, b.tasks, b.group_cursor, zero_words);
+          return;
+        }
+      }
+      const u64 items = 8 * static_cast<u64>((chunks + 7) / 8) * num_cols;
+      const u32 recode_blocks = static_cast<u32>(items < (u64{1} << 30) ? items : (u64{1} << 30));
+      hipLaunchKernelGGL((k_recode<D>), dim3(recode_blocks), dim3(256), 0, fs, digits, b.cols,
+                         b.tasks, num_cols, chunks, b.group_cursor, zero_words);
+    });
+    ctx.timer.timed(timing, 2, fs, [&] {
+      u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
+      // pass 1a (+ 1b in the last workgroup of every task)
+      hipLaunchKernelGGL((k_group_hist<D>), dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
+                         part_lds, fs, b.group_cursor, b.big_tasks, digits, b.tasks, b.arrivals,
+                         b.group_start, b.group_chunk, b.bucket_count, bucket_fill,
+                         kStreamedSortRecords);
+      // pass 1c; all tasks of a launch share one variant: staged unless some column needs the direct form
+      if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
+        const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
+        hipLaunchKernelGGL((k_group_scatter<true, D>), dim3(plan.max_task_slices, num_tasks),
+                           dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, digits,
+                           b.tasks);
+      } else {
+        hipLaunchKernelGGL((k_group_scatter<false, D>), dim3(plan.max_task_slices, num_tasks),
+                           dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, digits,
+                           b.tasks);
+      }
+    });
+  };
+  if (plan.wide_digits) {
+    recode_and_partition(i32{});
+  } else {
+    recode_and_partition(i16{});
+  }
   u32 sort_launches = 0;
   ctx.timer.timed(timing, 2, fs, [&] {
     u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
-    // pass 1a (+ 1b in the last workgroup of every task)
-    hipLaunchKernelGGL(k_group_hist, dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
-                       part_lds, fs, b.group_cursor, b.big_tasks, b.digits, b.tasks, b.arrivals,
-                       b.group_start, b.group_chunk, b.bucket_count, bucket_fill,
-                       kStreamedSortRecords);
-    // pass 1c; all tasks of a launch share one variant: staged unless some column needs the direct form
-    if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
-      const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);
-      hipLaunchKernelGGL((k_group_scatter<true>), dim3(plan.max_task_slices, num_tasks),
-                         dim3(kSortThreads), staged_lds, fs, b.records, b.group_cursor, b.digits,
-                         b.tasks);
-    } else {
-      hipLaunchKernelGGL((k_group_scatter<false>), dim3(plan.max_task_slices, num_tasks),
-                         dim3(kSortThreads), part_lds, fs, b.records, b.group_cursor, b.digits,
-                         b.tasks);
-    }
     // pass 2, the oversized groups (skewed digits) in one more row of the same grid: their workers
     // meet at a barrier, so there may only be as many as the stream's compute units hold at once
     const u32 cus = ctx.stream_cus(fs);

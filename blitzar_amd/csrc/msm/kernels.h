@@ -37,6 +37,10 @@
 namespace bz {
 
 using i16 = int16_t;
+using i32 = int32_t;
+// Stored digits E = -D: int16 for window widths up to 16 (every launch without a window table), int32
+// for the merged tasks of wider window tables (msm_plan::wide_digits; class D below).
+template <class D> inline constexpr u32 kDigitsPerVector = 16 / sizeof(D); // per 16-byte load
 
 constexpr u32 kSortThreads = 1024;
 // k_reduce folds buckets with more than kReduceHeavyHeads head partials cooperatively, up to
@@ -228,8 +232,9 @@ void launch_prepare_addends(typename C::addend* d_addends, const void* d_api_gen
 // a row (ids = xcd mod 8) walk through the COLUMNS of one row chunk: the columns of a packed
 // fixed-base call are bit fields of the same rows (`row_stride` ~12 KiB at config 5), so every
 // lane touches its own cache line and the neighbouring columns find it in that XCD's L2.
-static __global__ void __launch_bounds__(256)
-    k_recode(i16* __restrict__ digits, const column_desc* __restrict__ columns,
+template <class D>
+__global__ void __launch_bounds__(256)
+    k_recode(D* __restrict__ digits, const column_desc* __restrict__ columns,
              const task_desc* __restrict__ tasks, u32 num_columns, u32 num_chunks,
              u32* __restrict__ zero, u64 zero_words) {
   // the group cursors of the sort start at zero: cleared here, by the first kernel of the call,
@@ -250,7 +255,7 @@ static __global__ void __launch_bounds__(256)
       // window tables: the column's windows are slices of one task, virtual row = window *
       // stride + row; rows between the column's end and the slice's are zero digits
       if (row >= col.merged_stride) continue;
-      i16* dst = digits + tasks[col.first_task].entry_base + row;
+      D* dst = digits + tasks[col.first_task].entry_base + row;
       digit_recoder rec;
       if (row < col.n) {
         rec.init(col.data + row * col.row_stride, col.bit_offset, col.bit_width, false,
@@ -259,7 +264,7 @@ static __global__ void __launch_bounds__(256)
       for (u32 wi = 0; wi < col.num_windows; ++wi) {
         const int d = row < col.n ? rec.next() : 0;
         if (wi + 1 < col.num_windows || row < col.n) {
-          dst[static_cast<u64>(wi) * col.merged_stride] = static_cast<i16>(-d);
+          dst[static_cast<u64>(wi) * col.merged_stride] = static_cast<D>(-d);
         }
       }
       continue;
@@ -270,7 +275,7 @@ static __global__ void __launch_bounds__(256)
              col.window_bits);
     for (u32 wi = 0; wi < col.num_windows; ++wi) {
       const int d = rec.next();
-      digits[tasks[col.first_task + wi].entry_base + row] = static_cast<i16>(-d);
+      digits[tasks[col.first_task + wi].entry_base + row] = static_cast<D>(-d);
     }
   }
 }
@@ -315,8 +320,9 @@ static __global__ void __launch_bounds__(256)
 // span into LDS with aligned 16-byte loads (coalesced along the row), then every wavefront takes
 // columns of the range, lane = row, and recodes from LDS; a task's 64 digits leave as one 128-byte
 // line.
-static __global__ void __launch_bounds__(kPackedRecodeThreads)
-    k_recode_packed(i16* __restrict__ digits, const column_desc* __restrict__ columns,
+template <class D>
+__global__ void __launch_bounds__(kPackedRecodeThreads)
+    k_recode_packed(D* __restrict__ digits, const column_desc* __restrict__ columns,
                     const task_desc* __restrict__ tasks, const recode_range* __restrict__ ranges,
                     u32 num_ranges, u64 row_stride, u64 max_rows, u64 data_rows,
                     u32* __restrict__ zero, u64 zero_words) {
@@ -360,7 +366,7 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
       const u64 row = row0 + lane;
       if (col.merged_stride != 0 && lane < rows && row >= col.n && row < col.merged_stride) {
         // window tables: zero digits between the column's end and the slice's
-        i16* dst = digits + tasks[col.first_task].entry_base + row;
+        D* dst = digits + tasks[col.first_task].entry_base + row;
         for (u32 wi = 0; wi + 1 < col.num_windows; ++wi) {
           dst[static_cast<u64>(wi) * col.merged_stride] = 0;
         }
@@ -382,7 +388,7 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
                              ? tasks[col.first_task].entry_base +
                                    static_cast<u64>(wi) * col.merged_stride + row
                              : tasks[col.first_task + wi].entry_base + row;
-          digits[at] = static_cast<i16>(-d);
+          digits[at] = static_cast<D>(-d);
         }
       }
     }
@@ -396,20 +402,33 @@ static __global__ void __launch_bounds__(kPackedRecodeThreads)
 //--------------------------------------------------------------------------------------------------
 // Both partition sweeps visit the digits of a (task, slice) in the same vectorised order.  `fn(r, e)`
 // is called for every non-zero stored digit e = -D of row r (relative to the slice).
-template <class F>
-__device__ __forceinline__ void for_each_slice_digit(const i16* __restrict__ dig, u32 rows, F&& fn) {
+// the stored digits E = -D of one 16-byte vector: eight int16 or four int32
+template <class D>
+__device__ __forceinline__ void unpack_digits(const uint4& pack, int e[kDigitsPerVector<D>]) {
+  const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
+  if constexpr (sizeof(D) == 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = static_cast<i16>(words[k >> 1] >> (16 * (k & 1)));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = static_cast<int>(words[k]);
+  }
+}
+
+template <class D, class F>
+__device__ __forceinline__ void for_each_slice_digit(const D* __restrict__ dig, u32 rows, F&& fn) {
   // slices start at multiples of 8 rows and entry ranges are padded to multiples of 8
   // entries, so 16-byte vector loads are aligned and in bounds
-  const u32 nvec = (rows + 7) / 8;
+  constexpr u32 V = kDigitsPerVector<D>;
+  const u32 nvec = (rows + V - 1) / V;
   const uint4* dig4 = reinterpret_cast<const uint4*>(dig);
   for (u32 v = threadIdx.x; v < nvec; v += kSortThreads) {
-    const uint4 pack = dig4[v];
-    const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
+    int e[V];
+    unpack_digits<D>(dig4[v], e);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u32 r = v * 8 + k;
-      const int e = static_cast<i16>(words[k >> 1] >> (16 * (k & 1)));
-      if (r < rows && e != 0) fn(r, e);
+    for (u32 k = 0; k < V; ++k) {
+      const u32 r = v * V + k;
+      if (r < rows && e[k] != 0) fn(r, e[k]);
     }
   }
 }
@@ -505,9 +524,10 @@ group_offsets_block(const task_desc& task, u32 task_index, u32* __restrict__ gro
 // (2^s consecutive buckets): LDS histogram, one global atomic per populated group.
 // The workgroup that finishes LAST on a task (a ticket per task, zeroed with the group cursors by
 // the recode kernel) goes on to run pass 1b for it: no 17-workgroup launch of its own (~5 us).
-static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
+template <class D>
+__global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_hist(u32* __restrict__ group_total, u32* __restrict__ big_tasks,
-                 const i16* __restrict__ digits, const task_desc* __restrict__ tasks,
+                 const D* __restrict__ digits, const task_desc* __restrict__ tasks,
                  u32* __restrict__ arrivals, u32* __restrict__ group_start,
                  u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
                  u32* __restrict__ bucket_fill, u32 stream_limit) {
@@ -525,7 +545,7 @@ static __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two wo
   const u64 row0 = static_cast<u64>(slice) * task.slice_rows;
   const u32 rows =
       static_cast<u32>(task.rows - row0 < task.slice_rows ? task.rows - row0 : task.slice_rows);
-  for_each_slice_digit(digits + task.entry_base + row0, rows, [&](u32, int e) {
+  for_each_slice_digit<D>(digits + task.entry_base + row0, rows, [&](u32, int e) {
     const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
     atomicAdd(&lds[(mag - 1) >> s], 1u);
   });
@@ -563,13 +583,6 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// the eight stored digits E = -D of one 16-byte vector
-__device__ __forceinline__ void unpack_digits(const uint4& pack, int e[8]) {
-  const u32 words[4] = {pack.x, pack.y, pack.z, pack.w};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) e[k] = static_cast<i16>(words[k >> 1] >> (16 * (k & 1)));
-}
-
 // Pass 1c.  Every non-zero digit of the slice becomes one 32-bit record in its group's piece of
 // the record list:
 //   record = (digit negative) << 31 | (bucket mod 2^s) << (31 - s) | row        (row < 2^(31-s))
@@ -584,10 +597,13 @@ __device__ __forceinline__ void unpack_digits(const uint4& pack, int e[8]) {
 // Staged slices are short enough for every digit vector to stay in registers, so the counting pass
 // keeps what its LDS atomic returns -- the digit's rank inside its group -- and the second pass places
 // the record at local_start[group] + rank with a plain LDS read instead of a second atomic.
-template <bool Staged>
+template <bool Staged, class D>
 __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_scatter(u32* __restrict__ records, u32* __restrict__ group_cursor,
-                    const i16* __restrict__ digits, const task_desc* __restrict__ tasks) {
+                    const D* __restrict__ digits, const task_desc* __restrict__ tasks) {
+  constexpr u32 V = kDigitsPerVector<D>;                   // digits per 16-byte vector: 8 or 4
+  constexpr u32 H = kStagedSliceRows / (V * kSortThreads); // vectors a thread holds: 2 or 4
+  static_assert(H * V * kSortThreads == kStagedSliceRows);
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   __shared__ u32 wave_sums[kSortThreads / 64];
   const task_desc task = tasks[blockIdx.y];
@@ -604,40 +620,46 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   const u64 row0 = static_cast<u64>(slice) * task.slice_rows;
   const u32 rows =
       static_cast<u32>(task.rows - row0 < task.slice_rows ? task.rows - row0 : task.slice_rows);
-  const u32 nvec = (rows + 7) / 8;
+  const u32 nvec = (rows + V - 1) / V;
   const uint4* dig4 = reinterpret_cast<const uint4*>(digits + task.entry_base + row0);
-  // the first two vectors of every thread stay in registers (all of them at 16384-row slices)
-  uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-  if (tid < nvec) held[0] = dig4[tid];
-  if (tid + kSortThreads < nvec) held[1] = dig4[tid + kSortThreads];
-  auto vector_at = [&](u32 v) {
-    return v == tid ? held[0] : (v == tid + kSortThreads ? held[1] : dig4[v]);
-  };
-  u32 rank[2][8];
+  // the first H vectors of every thread stay in registers (all of them at 16384-row slices)
+  uint4 held[H];
+#pragma unroll
+  for (u32 j = 0; j < H; ++j) {
+    held[j] = make_uint4(0, 0, 0, 0);
+    if (tid + j * kSortThreads < nvec) held[j] = dig4[tid + j * kSortThreads];
+  }
+  u32 rank[H][V];
   if constexpr (Staged) {
-    static_assert(kStagedSliceRows <= 2 * 8 * kSortThreads);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const u32 v = tid + static_cast<u32>(j) * kSortThreads;
-      int e[8];
-      unpack_digits(held[j], e);
+    for (u32 j = 0; j < H; ++j) {
+      const u32 v = tid + j * kSortThreads;
+      int e[V];
+      unpack_digits<D>(held[j], e);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (u32 k = 0; k < V; ++k) {
         const u32 mag = e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k]);
         rank[j][k] = 0;
-        if (v * 8 + k < rows && e[k] != 0) rank[j][k] = atomicAdd(&cursor[(mag - 1) >> s], 1u);
+        if (v * V + k < rows && e[k] != 0) rank[j][k] = atomicAdd(&cursor[(mag - 1) >> s], 1u);
       }
     }
   } else {
-    for (u32 v = tid; v < nvec; v += kSortThreads) {
-      int e[8];
-      unpack_digits(vector_at(v), e);
+    // (held[] is only ever indexed with compile-time constants: a run-time index would park it in
+    // scratch)
+    auto count_vector = [&](const uint4& vec, u32 v) {
+      int e[V];
+      unpack_digits<D>(vec, e);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (u32 k = 0; k < V; ++k) {
         const u32 mag = e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k]);
-        if (v * 8 + k < rows && e[k] != 0) atomicAdd(&cursor[(mag - 1) >> s], 1u);
+        if (v * V + k < rows && e[k] != 0) atomicAdd(&cursor[(mag - 1) >> s], 1u);
       }
+    };
+#pragma unroll
+    for (u32 j = 0; j < H; ++j) {
+      if (tid + j * kSortThreads < nvec) count_vector(held[j], tid + j * kSortThreads);
     }
+    for (u32 v = tid + H * kSortThreads; v < nvec; v += kSortThreads) count_vector(dig4[v], v);
   }
   lds_barrier();
   u32* cur = group_cursor + task.group_base;
@@ -670,23 +692,23 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
   const u32 in_group = (1u << s) - 1, shift = 31 - s;
   if constexpr (Staged) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const u32 v = tid + static_cast<u32>(j) * kSortThreads;
-      int e[8];
-      unpack_digits(held[j], e);
-      u32 pos[8], rec[8];
-      bool take[8];
+    for (u32 j = 0; j < H; ++j) {
+      const u32 v = tid + j * kSortThreads;
+      int e[V];
+      unpack_digits<D>(held[j], e);
+      u32 pos[V], rec[V];
+      bool take[V];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (u32 k = 0; k < V; ++k) {
         // E = -D: positive E means the digit is negative -> subtract the generator
         const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
-        take[k] = v * 8 + k < rows && e[k] != 0;
+        take[k] = v * V + k < rows && e[k] != 0;
         rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
-                 (static_cast<u32>(row0) + v * 8 + k);
+                 (static_cast<u32>(row0) + v * V + k);
         pos[k] = take[k] ? local_start[bucket >> s] + rank[j][k] : 0;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (u32 k = 0; k < V; ++k) {
         if (take[k]) staging[pos[k]] = rec[k];
       }
     }
@@ -697,25 +719,30 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
       for (u32 i = lane; i < count; i += 64) dst[i] = staging[from + i];
     }
   } else {
-    for (u32 v = tid; v < nvec; v += kSortThreads) {
-      int e[8];
-      unpack_digits(vector_at(v), e);
-      u32 pos[8], rec[8];
-      bool take[8];
+    auto place_vector = [&](const uint4& vec, u32 v) {
+      int e[V];
+      unpack_digits<D>(vec, e);
+      u32 pos[V], rec[V];
+      bool take[V];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (u32 k = 0; k < V; ++k) {
         const u32 bucket = (e[k] < 0 ? static_cast<u32>(-e[k]) : static_cast<u32>(e[k])) - 1;
-        take[k] = v * 8 + k < rows && e[k] != 0;
+        take[k] = v * V + k < rows && e[k] != 0;
         rec[k] = (e[k] > 0 ? 0x80000000u : 0u) | ((bucket & in_group) << shift) |
-                 (static_cast<u32>(row0) + v * 8 + k);
+                 (static_cast<u32>(row0) + v * V + k);
         pos[k] = 0;
         if (take[k]) pos[k] = atomicAdd(&cursor[bucket >> s], 1u);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (u32 k = 0; k < V; ++k) {
         if (take[k]) out[pos[k]] = rec[k];
       }
+    };
+#pragma unroll
+    for (u32 j = 0; j < H; ++j) {
+      if (tid + j * kSortThreads < nvec) place_vector(held[j], tid + j * kSortThreads);
     }
+    for (u32 v = tid + H * kSortThreads; v < nvec; v += kSortThreads) place_vector(dig4[v], v);
   }
 }
 

@@ -131,6 +131,14 @@ struct column_desc {
 // entry's virtual row IS its row in the table and k_accumulate needs no change.  With every window
 // accumulating into the same 2^(bits-1) buckets, a column costs one bucket reduction instead of W
 // and its Horner chain over windows disappears.
+// `bits` may exceed 16 (kMaxTableWindowBits): a merged column's digits are then stored as 32-bit
+// words (msm_plan::wide_digits) -- one bucket set per column makes 2^17 buckets affordable where W
+// separate sets were not: 15 windows instead of 17 for 256-bit scalars at bits = 18.  The 32-bit
+// partition record (sign | bucket mod 2^s | row) bounds what is practical: a merged task of W x
+// stride virtual rows needs s >= bits - 11 record bits for at most 1024 bucket groups, i.e.
+// log2(W stride) + bits <= 42 (2^20 generators: bits = 18; 2^18: bits = 20); beyond that pass 1 falls
+// back to its direct form (one 4-byte store per record) -- correct, slower.
+constexpr u32 kMaxTableWindowBits = 20;
 struct window_table {
   u64 stride = 0;
   u32 windows = 0; // slices available
@@ -152,6 +160,7 @@ struct msm_plan {
   u32 max_task_groups = 0;
   u32 max_slice_rows = 0;
   u32 max_windows = 0;
+  bool wide_digits = false; // some column has c > 16: the digits of the launch are 32-bit words
   u32 segment_log2 = kSegmentLog2;               // sorted entries per k_accumulate lane
   u32 reduce_segment_log2 = kReduceSegmentLog2; // buckets per k_reduce lane (a block: 256 lanes)
   u32 reduce_block_buckets() const { return kReduceThreads << reduce_segment_log2; }
@@ -378,6 +387,7 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     if (geo.num_groups > plan.max_task_groups) plan.max_task_groups = geo.num_groups;
     if (geo.slice_rows > plan.max_slice_rows) plan.max_slice_rows = geo.slice_rows;
     if (w > plan.max_windows) plan.max_windows = w;
+    if (c > 16) plan.wide_digits = true;
     if (hc.n > plan.max_rows) plan.max_rows = hc.n;
     plan.columns.push_back(cd);
   }

@@ -172,14 +172,14 @@ def plan(ns, bit_widths, signed, max_window_bits=16, in_sequence=False):
     return per, totals
 
 
-def plan_tables(ns, bit_widths, signed, stride, windows, force=False, table_penalty=1.0):
+def plan_tables(ns, bit_widths, signed, stride, windows, force=False, table_penalty=1.0, bits=16):
     k = len(ns)
     per = np.zeros((k, 6), np.uint32)
-    totals = np.zeros(6, np.uint64)
+    totals = np.zeros(9, np.uint64)
     lib().bz_plan_tables(_p(per), _p(totals), _p(_c(ns)), _p(_c(bit_widths, np.uint32)),
                          _p(_c(signed, np.int32)), ctypes.c_uint32(k), ctypes.c_uint64(stride),
                          ctypes.c_uint32(windows), ctypes.c_int(1 if force else 0),
-                         ctypes.c_double(table_penalty))
+                         ctypes.c_double(table_penalty), ctypes.c_uint32(bits))
     return per, totals
 
 

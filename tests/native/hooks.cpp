@@ -204,10 +204,11 @@ void bz_plan(u32* per_column, u64* totals, const u64* n, const u32* bit_width, c
 
 // planner with a window table (msm/plan.h `window_table`): per column {window_bits, num_windows,
 // num_tasks, merged_stride, rows of the column's first task (low / high 32 bits)}; totals {tasks,
-// total_buckets, total_entries, max_task_rows, max_recode_rows, max_rows}
+// total_buckets, total_entries, max_task_rows, max_recode_rows, max_rows, wide_digits, group bits and
+// groups of the first merged task}
 void bz_plan_tables(u32* per_column, u64* totals, const u64* n, const u32* bit_width,
                     const int* is_signed, u32 num_columns, u64 stride, u32 windows, int force,
-                    double table_penalty) {
+                    double table_penalty, u32 table_bits) {
   std::vector<host_column> cols(num_columns);
   for (u32 i = 0; i < num_columns; ++i) {
     cols[i] = host_column{nullptr, n[i], (bit_width[i] + 7) / 8, 0, bit_width[i], is_signed[i] != 0};
@@ -218,6 +219,7 @@ void bz_plan_tables(u32* per_column, u64* totals, const u64* n, const u32* bit_w
   window_table tables;
   tables.stride = stride;
   tables.windows = windows;
+  tables.bits = table_bits;
   msm_plan plan = make_msm_plan(cols, tune, &tables);
   for (u32 i = 0; i < num_columns; ++i) {
     const column_desc& c = plan.columns[i];
@@ -235,6 +237,16 @@ void bz_plan_tables(u32* per_column, u64* totals, const u64* n, const u32* bit_w
   totals[3] = plan.max_task_rows;
   totals[4] = plan.max_recode_rows;
   totals[5] = plan.max_rows;
+  totals[6] = plan.wide_digits ? 1 : 0;
+  totals[7] = totals[8] = 0;
+  for (u32 i = 0; i < num_columns; ++i) {
+    const column_desc& c = plan.columns[i];
+    if (c.merged_stride != 0) {
+      totals[7] = plan.tasks[c.first_task].group_bits;
+      totals[8] = plan.tasks[c.first_task].num_groups;
+      break;
+    }
+  }
 }
 
 // column ranges of k_recode_packed (msm/plan.h): columns = bit fields at byte offsets `offset[i]`

@@ -134,7 +134,8 @@ def test_signed_digit_recoding_reconstructs_the_scalar():
         width = int(rng.integers(1, 257))
         offset = int(rng.integers(0, 8))
         signed = bool(rng.integers(0, 2)) and width <= 128 and width >= 2
-        c = int(rng.integers(2, 17 if not signed else 16))
+        # (widths above 16: the merged tasks of wide window tables, unsigned columns only)
+        c = int(rng.integers(2, 21 if not signed else 16))
         nbytes = (offset + width + 7) // 8
         raw = rng.integers(0, 256, nbytes, dtype=np.uint8)
         if rng.integers(0, 6) == 0:
@@ -583,3 +584,18 @@ def test_planner_window_tables():
     assert all(row[2] == 1 and row[0] == 16 for row in many.tolist())
     one, _ = hooks.plan_tables([1 << 20], [252], [0], 1 << 20, 17, table_penalty=1.15)
     assert one[0][2] == one[0][1] == 16 and one[0][3] == 0
+    # wide tables (bits > 16: 32-bit digits).  2^20 generators at 18 bits: 15 slices, a 256-bit
+    # column is ONE task of 14 * stride + n < 2^24 virtual rows and 2^17 buckets, which the 32-bit
+    # partition record still cuts into 1024 groups (sign + 7 bucket bits + 24 row bits)
+    big = 1 << 20
+    per, totals = hooks.plan_tables([big] * 8, [256] * 8, [0] * 8, big, 15, table_penalty=1.03, bits=18)
+    assert all(row[:4] == [18, 15, 1, big] for row in per.tolist())
+    assert int(totals[6]) == 1 and int(totals[7]) == 7 and int(totals[8]) == 1024
+    assert int(totals[1]) == 8 << 17                       # one set of 2^17 buckets per column
+    # ... and 2^18 generators at 20 bits: 13 slices, 2^19 buckets, 9 + 22 record bits, 1024 groups
+    per, totals = hooks.plan_tables([1 << 18] * 8, [256] * 8, [0] * 8, 1 << 18, 13, force=True, bits=20)
+    assert all(row[:4] == [20, 13, 1, 1 << 18] for row in per.tolist())
+    assert int(totals[6]) == 1 and int(totals[7]) == 9 and int(totals[8]) == 1024
+    # 16-bit tables keep int16 digits
+    _, totals = hooks.plan_tables([big] * 8, [256] * 8, [0] * 8, big, 17, table_penalty=1.03)
+    assert int(totals[6]) == 0

@@ -24,19 +24,19 @@ for step in "$@"; do
       (amd-smi static --asic --vbios --json; rocm-smi --showclocks --showpower --showcomputepartition \
         --showmemorypartition --showperflevel; nproc) > "$OUT/info.txt" 2>&1 ;;
     tests)
-      timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/gputests.log" 2>&1
+      timeout -k 10 600 python -m pytest tests -m gpu -x -q > "$OUT/gputests.log" 2>&1
       tail -3 "$OUT/gputests.log" | tee -a "$OUT/session.log" ;;
     tests:*)
-      timeout 900 python -m pytest tests -m gpu -x -q -k "${step#tests:}" > "$OUT/gputests_k.log" 2>&1
+      timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "${step#tests:}" > "$OUT/gputests_k.log" 2>&1
       tail -3 "$OUT/gputests_k.log" | tee -a "$OUT/session.log" ;;
     bench)
-      timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+      timeout -k 10 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
       echo "rc=$? $(wc -c < "$OUT/bench.json") bytes" | tee -a "$OUT/session.log" ;;
     bench-quick)
       timeout 600 python bench.py --no-configs --skip-headline-check > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
       echo "rc=$?" | tee -a "$OUT/session.log" ;;
     stats)
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_stats" -- \
+      (cd /tmp && timeout -k 10 420 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_stats" -- \
         python "$OLDPWD/bench.py" --no-aux --skip-headline-check > "$OLDPWD/$OUT/stats_bench.json" 2> "$OLDPWD/$OUT/stats.err")
       find "$OUT/prof_stats" -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
       echo "rc=$?" | tee -a "$OUT/session.log" ;;
@@ -44,7 +44,7 @@ for step in "$@"; do
       for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
                  "FETCH_SIZE" "WRITE_SIZE"; do
         name=$(echo $set | cut -d' ' -f1)
-        (cd /tmp && timeout 900 rocprofv3 --pmc $set -d "$OLDPWD/$OUT/pmc_$name" -- \
+        (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set -d "$OLDPWD/$OUT/pmc_$name" -- \
           python "$OLDPWD/bench.py" --no-aux --skip-headline-check --steps 5 --config-steps 1 \
           > "$OLDPWD/$OUT/pmc_$name.json" 2> "$OLDPWD/$OUT/pmc_$name.err")
         echo "pmc $name rc=$?" | tee -a "$OUT/session.log"
@@ -58,10 +58,10 @@ for step in "$@"; do
       done < "${step#ab:}"
       tail -40 "$OUT/ab.log" ;;
     grid)
-      timeout 1200 python tools/grid_bench.py --out "$OUT/grid.json" > "$OUT/grid.log" 2>&1
+      timeout -k 10 420 python tools/grid_bench.py --out "$OUT/grid.json" > "$OUT/grid.log" 2>&1
       echo "rc=$?" | tee -a "$OUT/session.log"; tail -5 "$OUT/grid.log" ;;
     cmd:*)
-      bash "${step#cmd:}" > "$OUT/cmd_$(basename "${step#cmd:}").log" 2>&1
+      timeout -k 10 300 bash "${step#cmd:}" "$TAG" > "$OUT/cmd_$(basename "${step#cmd:}").log" 2>&1
       echo "rc=$?" | tee -a "$OUT/session.log" ;;
     *) echo "unknown step $step" | tee -a "$OUT/session.log" ;;
   esac

@@ -101,8 +101,12 @@ int main() {
   uint8_t* d_table = nullptr;
   uint32_t* d_out = nullptr;
   CHECK(hipMalloc(&d_table, big + 256));
-  CHECK(hipMalloc(&d_out, sizeof(uint32_t) * kBlocks * kThreads));
-  CHECK(hipMemset(d_table, 0x5a, big + 256));
+  CHECK(hipMalloc(&d_out, sizeof(uint32_t) * kBlocks * 4 * kThreads)); // (k_stream: 4 x the blocks)
+  // (in pieces: a single fill of 2 GiB and more faulted on this runtime)
+  for (uint64_t off = 0; off < big; off += uint64_t{1} << 29) {
+    CHECK(hipMemset(d_table + off, 0x5a, uint64_t{1} << 29));
+  }
+  CHECK(hipDeviceSynchronize());
   std::printf("[");
   if (run<128, 26>(d_out, d_table, true)) return 1;
   if (run<96, 26>(d_out, d_table, false)) return 1;
