@@ -34,13 +34,19 @@ namespace bz {
 // 2^(bits w) multiples follow, `stride` rows apart -- 17 x the memory at bits = 16 (2.2 GB for 2^20
 // curve25519 generators), 15 x at bits = 18 -- which buys one bucket reduction per column instead of
 // one per window and no Horner chain.
-// Window width of the table: with ONE bucket set per column, 2^17 buckets are affordable where W
-// separate sets were not, so sets of 2^18 generators or more take bits = 18 (256-bit columns: 15
-// windows instead of 17; by the planner's cost model W n + 3.5 x 2^(bits - 1) that is 15.4 n against
-// 17.1 n at n = 2^20, 16.75 n against 17.4 n at 2^18, and 22 n against 18.75 n at 2^16, which
-// therefore stays at 16).  BLITZAR_AMD_WINDOW_TABLE_BITS (16 .. 20) overrides (tests, A/B runs).
+// Window width of the table.  With ONE bucket set per column more buckets are affordable than with W
+// separate sets, and wider windows mean fewer slices to add (256-bit columns: 17 slices at 16 bits,
+// 16 at 17, 15 at 18).  Measured on MI355X (profiles/round5_ab_wide_tables_and_short_columns.log, ms
+// per call lone / in sequence): bn254, 8 columns x 2^20 rows: 16 bits 11.80 / 10.80, 17 bits 11.05 /
+// 10.65, 18 bits 11.63 / 11.19, 19 bits 12.6 / 12.0 -- the additions saved (k_accumulate 9.2 -> 9.0 ms)
+// are partly eaten by the sort, whose groups no longer fit the LDS stage once a merged task has 2^17
+// buckets over 2^24 virtual rows (0.65 -> 1.35 / 1.67 ms), while k_reduce gains (1.5 -> 0.4 ms: fewer
+// head partials per bucket); grumpkin, 64 columns x 2^18 rows: 21.0 / 20.9 / 22.5 ms at 16 / 17 / 18 bits
+// and 27.1 at 20; curve25519, 8 x 2^20: 6.2 -> 7.0 ms at 18.  So: 17 bits for Weierstrass sets of 2^20
+// generators or more, 16 for everything else.  BLITZAR_AMD_WINDOW_TABLE_BITS (16 .. 20) overrides
+// (tests, A/B runs).
 constexpr u64 kWindowTableMinGenerators = u64{1} << 14;
-constexpr u64 kWideWindowTableMinGenerators = u64{1} << 18;
+constexpr u64 kWideWindowTableMinGenerators = u64{1} << 20;
 inline u32 window_table_slices(u32 bits) { return (256 + 1 + bits - 1) / bits; } // + the carry
 struct resident_table {
   void* d_addends = nullptr;
@@ -63,7 +69,7 @@ struct resident_table {
     if (const char* v = std::getenv("BLITZAR_AMD_WINDOW_TABLE_MIN")) {
       least = std::strtoull(v, nullptr, 10); // tests: tables for small sets too
     }
-    u32 bits = count >= kWideWindowTableMinGenerators ? 18 : 16;
+    u32 bits = vt.curve_id != 0 && count >= kWideWindowTableMinGenerators ? 17 : 16;
     if (const char* v = std::getenv("BLITZAR_AMD_WINDOW_TABLE_BITS")) {
       const unsigned long b = std::strtoul(v, nullptr, 10);
       BZ_RELEASE_ASSERT(b >= 16 && b <= kMaxTableWindowBits,

@@ -642,6 +642,14 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                                c.num_windows == 17 &&
                                (reinterpret_cast<uintptr_t>(c.data) & 15) == 0));
   }
+  // A bucket group of more records than pass 2 stages in LDS is streamed by ONE workgroup (up to 16 x
+  // the capacity) or cut into chunks for the workers of the chunked path.  Streaming wins where
+  // there are many such groups (2^20 rows of 252-bit scalars: 16 of them per column, sort 0.128 against
+  // 0.157 ms chunked, profiles/round4_ab_sort_stream_limit.log); in a short launch there is ONE --
+  // the top window's 2^16 records in a handful of buckets -- and eleven serial rounds of a single
+  // workgroup are most of the sort (2^16 rows: 0.090 ms): chunks over the workers instead.
+  const u32 stream_limit =
+      plan.total_entries <= (u64{1} << 22) ? kLocalSortCapacity : kStreamedSortRecords;
   // the kernels that write / read the stored digits, for the launch's digit type
   auto recode_and_partition = [&](auto digit_tag) {
     using D = decltype(digit_tag);
@@ -674,8 +682,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       // pass 1a (+ 1b in the last workgroup of every task)
       hipLaunchKernelGGL((k_group_hist<D>), dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
                          part_lds, fs, b.group_cursor, b.big_tasks, digits, b.tasks, b.arrivals,
-                         b.group_start, b.group_chunk, b.bucket_count, bucket_fill,
-                         kStreamedSortRecords);
+                         b.group_start, b.group_chunk, b.bucket_count, bucket_fill, stream_limit);
       // pass 1c; all tasks of a launch share one variant: staged unless some column needs the direct form
       if (plan.max_task_groups <= kMaxStagedGroups && plan.max_slice_rows <= kStagedSliceRows) {
         const size_t staged_lds = sizeof(u32) * (3 * plan.max_task_groups + 1 + kStagedSliceRows);

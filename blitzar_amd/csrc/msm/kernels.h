@@ -1436,6 +1436,12 @@ __global__ void __launch_bounds__(kReduceThreads)
     return;
   }
   const u32 seg_first = block_first + tid * lane_buckets;
+  // lanes that own buckets, rounded up to a power of two (at least one wavefront): a task of few
+  // buckets (many short columns: 256 buckets per task at 9-bit windows) fills a quarter of the
+  // workgroup, and the scan and the tree below only involve these lanes -- the other wavefronts hold
+  // identities and skip their additions
+  u32 active = 64;
+  while (active < kReduceThreads && active * lane_buckets < block_end - block_first) active <<= 1;
   const point* bs = bucket_sums + task.bucket_base;
   const point* hd = heads + task.segment_base;
   // Heavy buckets first.  A bucket that holds a large share of a skewed column (constants,
@@ -1506,19 +1512,19 @@ __global__ void __launch_bounds__(kReduceThreads)
     }
   }
   if constexpr (Scan) {
-    // inclusive suffix scan of s over the 256 lanes
+    // inclusive suffix scan of s over the active lanes
     point x = s;
-    for (u32 d = 1; d < kReduceThreads; d <<= 1) {
+    for (u32 d = 1; d < active; d <<= 1) {
       tree[tid] = x;
       __syncthreads();
-      if (tid + d < kReduceThreads) x = C::add(x, tree[tid + d]);
+      if (tid + d < active) x = C::add(x, tree[tid + d]);
       __syncthreads();
     }
     // v_t = r_t + 2^lane_log2 * suffix_t (t >= 1), folded by the tree
-    if (tid != 0) r = C::add(r, C::dbl_n(x, static_cast<int>(lane_log2)));
+    if (tid != 0 && tid < active) r = C::add(r, C::dbl_n(x, static_cast<int>(lane_log2)));
     tree[tid] = r;
     __syncthreads();
-    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+    for (u32 stride = active / 2; stride > 0; stride >>= 1) {
       if (tid < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
       __syncthreads();
     }
@@ -1550,7 +1556,7 @@ __global__ void __launch_bounds__(kReduceThreads)
     }
     tree[tid] = contrib;
     __syncthreads();
-    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+    for (u32 stride = active / 2; stride > 0; stride >>= 1) {
       if (tid < stride) tree[tid] = C::add(tree[tid], tree[tid + stride]);
       __syncthreads();
     }

@@ -36,9 +36,16 @@ constexpr u32 kSegmentLog2Max = 7;
 // 18 M entries, is not)
 constexpr u64 kSegmentFillLanes = u64{1} << 19;
 constexpr u32 kSegmentEntries = 1u << kSegmentLog2;
-inline u32 choose_segment_log2(u64 total_entries) {
+constexpr u32 kSegmentLog2Min = 3;
+// `mean_task_rows`: a task's lanes are rows / 2^s of ONE workgroup row of k_accumulate's grid, so short
+// tasks must keep s small enough for whole wavefronts: 1024 columns x 4096 rows (the reference's
+// bucket_method2 regime) chose 128 entries per lane from its 1.2e8 entries and ran every task on HALF
+// a wavefront -- k_accumulate 10.8 ms against 5.7 ms at 32 entries per lane
+// (profiles/round5_ab_wide_tables_and_short_columns.log).  At least 128 lanes per task where the rows allow it.
+inline u32 choose_segment_log2(u64 total_entries, u64 mean_task_rows = ~u64{0}) {
   u32 s = kSegmentLog2;
   while (s < kSegmentLog2Max && (total_entries >> (s + 1)) >= kSegmentFillLanes) ++s;
+  while (s > kSegmentLog2Min && (mean_task_rows >> s) < 128) --s;
   return s;
 }
 constexpr u32 kStagedSliceRows = 1u << 14; // rows per partition workgroup: staged in LDS / direct
@@ -75,13 +82,25 @@ constexpr u64 kReduceFillLanes = 131072;
 // config 2 0.987 -> 0.978 ms, on resident generators 0.892 -> 0.871, one bls12-381 column of 2^22
 // rows 12.6 -> 11.8; a lone k_reduce of this geometry takes 0.38 instead of 0.20 ms, which is why
 // lone calls keep the shorter chain).
+// `lone_latency`: a launch of few columns outside the throughput mode whose buckets fit the machine
+// at 2 per lane (<= 2^18 buckets: 512 workgroups): k_reduce is then the longer of a lone call's two
+// tail chains and 2 buckets per lane halve it -- 2^16 curve25519 rows: k_reduce 0.166 -> 0.090 ms, the
+// lone call 0.55 -> 0.47; in a sequence the same geometry costs 3 % (more workgroups beside the next
+// call), and at 2^20 rows twice the workgroups no longer fit (0.19 -> 0.31 ms): both keep theirs.
+// `throughput`: a launch of many columns.  Its small tasks (256 buckets at 9-bit windows: thousands of
+// short columns) keep at least ONE wavefront's worth of lanes with several buckets each -- k_reduce
+// runs its scan and tree over the lanes in use only, so 64 lanes x 4 buckets cost a third of the
+// additions of 256 lanes x 1 bucket; a lone narrow column keeps the shortest chain (below).
 inline u32 choose_reduce_segment_log2(u64 total_buckets, u32 max_task_buckets,
-                                      bool in_sequence = false) {
+                                      bool in_sequence = false, bool lone_latency = false,
+                                      bool throughput = false) {
   u32 s = kReduceSegmentLog2 + (in_sequence ? 1 : 0);
+  if (lone_latency && total_buckets <= (u64{1} << 18)) s = 1;
+  const u64 lanes_min = throughput ? 64 : kReduceThreads;
   // narrow columns (bytes, booleans: 128..1024 buckets per task) have one block per task anyway:
   // fewer buckets per lane, down to one, shorten its chain (a 1-byte column of 2^20 rows: k_reduce
   // 0.25 -> 0.1 ms of a 0.6 ms call)
-  while (s > 0 && (static_cast<u64>(kReduceThreads) << s) > max_task_buckets) --s;
+  while (s > 0 && (lanes_min << s) > max_task_buckets) --s;
   // ... as long as the largest task still fills a block's 256 lanes (idle waves of a block hold
   // registers the other blocks of the CU could use)
   while (s < kReduceSegmentLog2Max && (total_buckets >> (s + 1)) >= kReduceFillLanes &&
@@ -320,14 +339,17 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     return sh;
   };
   // entries per accumulation lane: one value for the launch, from its total number of entries
-  u64 launch_entries = 0;
+  u64 launch_entries = 0, launch_tasks = 0;
   for (const auto& hc : cols) {
     if (hc.n == 0) continue;
     const column_shape sh = shape_of(hc);
     launch_entries += sh.task_rows * (sh.merged ? 1 : sh.w);
+    launch_tasks += sh.merged ? 1 : sh.w;
   }
-  plan.segment_log2 = tune.force_segment_log2 != 0 ? tune.force_segment_log2
-                                                   : choose_segment_log2(launch_entries);
+  plan.segment_log2 =
+      tune.force_segment_log2 != 0
+          ? tune.force_segment_log2
+          : choose_segment_log2(launch_entries, launch_tasks != 0 ? launch_entries / launch_tasks : 0);
   const u64 seg_entries = u64{1} << plan.segment_log2;
   for (size_t ci = 0; ci < cols.size(); ++ci) {
     const host_column& hc = cols[ci];
@@ -397,7 +419,9 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
                                        plan.total_buckets, plan.max_task_buckets,
                                        // (short columns are all tail even in a sequence: 2^16 rows
                                        // 0.285 -> 0.351 ms per call with the longer chain)
-                                       tune.in_sequence && plan.total_entries >= (u64{1} << 23));
+                                       tune.in_sequence && plan.total_entries >= (u64{1} << 23),
+                                       !tune.in_sequence && nonempty < tune.throughput_columns,
+                                       nonempty >= tune.throughput_columns);
   return plan;
 }
 

@@ -58,11 +58,35 @@ def main():
             v = counters[k].get(c)
             return sum(v) / len(v) if v else None
 
+        # What FETCH_SIZE has to be multiplied by, per access pattern (profiles/fetch_calibration.json,
+        # tools/ubench/gather_fetch.hip under rocprofv3 --pmc FETCH_SIZE, round 5): the counter tallies
+        # a 128-byte request at 64 bytes -- wide streaming reads AND whole-line 128-byte row gathers
+        # (curve25519 addends) read x 2 -- but 64- and 32-byte requests at face value: the 64-byte rows
+        # of bn254 / grumpkin and the 96-byte rows of bls12-381 (64 + 32) read x 1.
+        import json as _json
+        cal_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fetch_calibration.json")
+        patterns = _json.load(open(cal_path))["patterns"] if os.path.exists(cal_path) else {}
+
+        def pattern_factor(row_bytes, default):
+            # the table beyond the Infinity Cache: no L2 hits hiding requests from the counter
+            e = patterns.get(f"k_gather<{row_bytes}, 31>")
+            return round(e["factor"], 2) if e and e.get("factor") else default
+
+        def read_factor(k):
+            if k.startswith("k_accumulate<bz::bn254") or k.startswith("k_accumulate<bz::grumpkin"):
+                return pattern_factor(64, 1.0)
+            if k.startswith("k_accumulate<bz::bls12_381"):
+                return pattern_factor(96, 1.0)
+            if k.startswith("k_accumulate<bz::ed25519"):
+                return pattern_factor(128, 2.0)
+            return 2.0
+
         def kernel_entry(k):
             f, w = avg(k, "FETCH_SIZE"), avg(k, "WRITE_SIZE")
             e = {"fetch_kib": f, "write_kib": w, "launches_averaged": len(counters[k].get("FETCH_SIZE", []))}
             if f is not None and w is not None:
-                e["bytes_per_launch"] = (2 * f + w) * 1024
+                e["fetch_factor"] = read_factor(k)
+                e["bytes_per_launch"] = (e["fetch_factor"] * f + w) * 1024
                 e["raw_bytes_per_launch"] = (f + w) * 1024
             act, cyc = avg(k, "SQ_ACTIVE_INST_VALU"), avg(k, "GRBM_GUI_ACTIVE")
             if act is not None and cyc:
@@ -103,8 +127,10 @@ def main():
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                              "tools/prof/run_pmc.sh) of `python bench.py` on MI355X, summarised "
                              "by profiles/summarize_pmc.py from " + root,
-                   "note": "HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024): "
-                           "the gfx950 correction of MI355X_MICROARCH.md (HBM), confirmed in the "
+                   "note": "HBM-side bytes per launch = fetch_factor x FETCH_SIZE + WRITE_SIZE (KiB x "
+                           "1024); fetch_factor per access pattern from profiles/fetch_calibration.json "
+                           "(128-byte requests are tallied at 64 bytes: x 2 for streaming reads and "
+                           "128-byte row gathers; 64- and 96-byte row gathers x 1), cross-checked in the "
                            "same run on k_prepare_addends whose bytes are known (see "
                            "`calibration`).  The bucket method gathers every 128-byte addend once "
                            "per window: 16 x 2^20 x 128 B = 2.15 GB plus 0.2 GB of indices and "

@@ -210,7 +210,20 @@ def test_planner_invariants():
     _, totals = hooks.plan([1 << 20], [8], [0])
     assert totals[6:].tolist() == [5, 0]
     _, totals = hooks.plan([1 << 20], [32], [0])
-    assert totals[6:].tolist() == [5, 2]
+    assert totals[6:].tolist() == [5, 1]     # (a lone launch of few buckets: two per lane, below)
+    # a LONE short launch (<= 2^18 buckets in all) takes two buckets per reduce lane -- k_reduce is the
+    # longer of its two tail chains -- and keeps the sequence's geometry in throughput mode
+    _, totals = hooks.plan([1 << 16], [256], [0])
+    assert totals[7] == 1
+    _, totals = hooks.plan([1 << 16], [256], [0], in_sequence=True)
+    assert totals[7] == 3
+    # many short columns (the reference's bucket_method2 regime): entries per accumulation lane follow
+    # the rows of a task (4096 rows: 128 lanes x 32 entries, never half a wavefront of 128-entry lanes),
+    # and the 256 buckets of a task go to 64 reduce lanes x 4
+    per, totals = hooks.plan([4096] * 1024, [256] * 1024, [0] * 1024)
+    assert per[0][0] == 9 and totals[6:].tolist() == [5, 2]
+    _, totals = hooks.plan([1024] * 1024, [256] * 1024, [0] * 1024)
+    assert totals[6] == 3
     # blocks of the bucket reduction stay full: 2^13 buckets per task leave 32 per lane
     per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256, max_window_bits=14)
     assert per[0][0] == 14 and totals[6:].tolist() == [7, 5]

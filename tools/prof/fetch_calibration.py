@@ -25,13 +25,21 @@ def main():
     per_dispatch = collections.defaultdict(float)
     for dirpath, _, files in os.walk(root):
         for f in files:
-            if not f.endswith("counter_collection.csv"):
-                continue
-            for r in csv.DictReader(open(os.path.join(dirpath, f))):
-                if r["Counter_Name"] != "FETCH_SIZE":
-                    continue
-                name = r["Kernel_Name"].replace("void ", "").split("(")[0].strip()
-                per_dispatch[(name, r["Dispatch_Id"])] += float(r["Counter_Value"])
+            path = os.path.join(dirpath, f)
+            if f.endswith("counter_collection.csv"):
+                for r in csv.DictReader(open(path)):
+                    if r["Counter_Name"] != "FETCH_SIZE":
+                        continue
+                    name = r["Kernel_Name"].replace("void ", "").split("(")[0].strip()
+                    per_dispatch[(name, r["Dispatch_Id"])] += float(r["Counter_Value"])
+            elif f.endswith(".db"):  # rocprofv3's default output: a rocpd sqlite database
+                import sqlite3
+                db = sqlite3.connect(path)
+                for name, dispatch, value in db.execute(
+                        "select kernel_name, dispatch_id, value from counters_collection "
+                        "where counter_name = 'FETCH_SIZE'"):
+                    name = name.replace("void ", "").split("(")[0].strip()
+                    per_dispatch[(name, dispatch)] += float(value)
     by_kernel = collections.defaultdict(list)
     for (name, _), v in per_dispatch.items():
         by_kernel[name].append(v)
