@@ -551,7 +551,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
                        static_cast<const point*>(nullptr), 1u, b.cols,
                        static_cast<const task_desc*>(nullptr), static_cast<const u32*>(nullptr), 0u,
-                       0u, 1, 1, plan.reduce_segment_log2);
+                       0u, 1, 1, plan.reduce_block_log2_over_256());
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipGetLastError());
     if (mode.piped) {
@@ -728,15 +728,23 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   if (mode.piped) ctx.acc_done[k & 3].wait(rs);
   wait_for(earlier(ctx.horner_done, 2), rs);
   ctx.timer.timed(timing, 4, rs, [&] {
-    const bool compact = ctx.compact_reduce == 1 ||
-                         (ctx.compact_reduce == 2 && ctx.slow_instruction_fetch &&
-                          num_cols < ctx.tuning.throughput_columns);
+    // (the compact form has 256-lane blocks only: launches of many small tasks keep the inlined one)
+    const bool compact = plan.reduce_threads == kReduceThreads &&
+                         (ctx.compact_reduce == 1 ||
+                          (ctx.compact_reduce == 2 && ctx.slow_instruction_fetch &&
+                           num_cols < ctx.tuning.throughput_columns));
     if (compact) {
       hipLaunchKernelGGL((k_reduce_compact<C>), dim3(b.partial_stride, num_tasks),
                          dim3(kReduceThreads), 0, rs, b.partials, b.partial_stride, b.task_total,
                          b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
     } else {
       auto launch = [&](auto scan) {
+        if (plan.reduce_threads == 64) {
+          hipLaunchKernelGGL((k_reduce<C, decltype(scan)::value, 64>), dim3(b.partial_stride, num_tasks),
+                             dim3(64), 0, rs, b.partials, b.partial_stride, b.task_total,
+                             b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
+          return;
+        }
         hipLaunchKernelGGL((k_reduce<C, decltype(scan)::value>), dim3(b.partial_stride, num_tasks),
                            dim3(kReduceThreads), 0, rs, b.partials, b.partial_stride, b.task_total,
                            b.bucket_sums, b.heads, b.bucket_end, b.tasks, plan.reduce_segment_log2);
@@ -760,7 +768,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
                        b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
-                       plan.reduce_segment_log2);
+                       plan.reduce_block_log2_over_256());
   });
   if (mode.piped) {
     ctx.horner_done[k & 3].record(hs);

@@ -1401,14 +1401,17 @@ __device__ __forceinline__ bucket_heads heads_of(u32 begin, u32 end, u32 seg_log
 // 0.82 -> 0.73 ms); a launch of many columns is bound by issue slots and barriers, not by the
 // length of a lane's chain, and runs 30-60 % LONGER under the scan (config 4: 32.7 -> 42.6 ms,
 // config 5: 13.7 -> 22.0, profiles/round4_ab_weierstrass_tails.txt)
-template <class C, bool Scan>
-__global__ void __launch_bounds__(kReduceThreads)
+// T: lanes per workgroup.  256, or 64 for launches of many SMALL tasks (256 buckets per task: thousands
+// of short columns): a 256-lane workgroup would run such a task on one wavefront while three idle ones
+// hold a CU's registers -- 1024 columns x 4096 rows: k_reduce 4.5 ms at two working wavefronts per CU.
+template <class C, bool Scan, u32 T = kReduceThreads>
+__global__ void __launch_bounds__(T)
     k_reduce(typename C::point* __restrict__ partials, u32 partial_stride,
              u32* __restrict__ task_total, const typename C::point* __restrict__ bucket_sums,
              const typename C::point* __restrict__ heads, const u32* __restrict__ bucket_end,
              const task_desc* __restrict__ tasks, u32 lane_log2) {
   using point = typename C::point;
-  __shared__ point tree[kReduceThreads];
+  __shared__ point tree[T];
   // a latency chain at one wavefront per SIMD: when it runs beside another batch's k_accumulate
   // (msm_context: throughput mode) its instructions go first, the accumulation fills the slots it leaves
   __builtin_amdgcn_s_setprio(BZ_REDUCE_PRIO);
@@ -1416,7 +1419,7 @@ __global__ void __launch_bounds__(kReduceThreads)
   const u32 nb = task.num_buckets;
   const u32 seg_log2 = task.segment_log2; // k_accumulate's segments: where the head partials are
   const u32 lane_buckets = 1u << lane_log2;
-  const u32 block_first = blockIdx.x * (kReduceThreads << lane_log2);
+  const u32 block_first = blockIdx.x * (T << lane_log2);
   if (block_first >= nb) return;
   const u32 tid = threadIdx.x;
   const u32* ends = bucket_end + task.bucket_base;
@@ -1428,8 +1431,8 @@ __global__ void __launch_bounds__(kReduceThreads)
   // use few of its buckets, the carry window): the identity, without the scan and the tree -- at
   // 252-bit scalars in 16-bit windows that is 30 of a column's 272 blocks, which otherwise share
   // compute units with blocks that have work
-  const u32 block_end = block_first + (kReduceThreads << lane_log2) < nb
-                            ? block_first + (kReduceThreads << lane_log2)
+  const u32 block_end = block_first + (T << lane_log2) < nb
+                            ? block_first + (T << lane_log2)
                             : nb;
   if (total == 0 || ends[block_end - 1] == (block_first == 0 ? 0 : ends[block_first - 1])) {
     if (tid == 0) *dst = C::identity();
@@ -1441,7 +1444,7 @@ __global__ void __launch_bounds__(kReduceThreads)
   // workgroup, and the scan and the tree below only involve these lanes -- the other wavefronts hold
   // identities and skip their additions
   u32 active = 64;
-  while (active < kReduceThreads && active * lane_buckets < block_end - block_first) active <<= 1;
+  while (active < T && active * lane_buckets < block_end - block_first) active <<= 1;
   const point* bs = bucket_sums + task.bucket_base;
   const point* hd = heads + task.segment_base;
   // Heavy buckets first.  A bucket that holds a large share of a skewed column (constants,
@@ -1473,13 +1476,13 @@ __global__ void __launch_bounds__(kReduceThreads)
     const bucket_heads list = heads_of(b == 0 ? 0 : ends[b - 1], ends[b], seg_log2);
     point part = C::identity();
     bool any = false;
-    for (u32 j = tid; j < list.count; j += kReduceThreads) {
+    for (u32 j = tid; j < list.count; j += T) {
       part = any ? C::add(part, hd[list.index(j)]) : hd[list.index(j)];
       any = true;
     }
     tree[tid] = part;
     __syncthreads();
-    for (u32 stride = kReduceThreads / 2; stride > 0; stride >>= 1) {
+    for (u32 stride = T / 2; stride > 0; stride >>= 1) {
       if (tid < stride && tid + stride < list.count) tree[tid] = C::add(tree[tid], tree[tid + stride]);
       __syncthreads();
     }

@@ -181,8 +181,13 @@ struct msm_plan {
   u32 max_windows = 0;
   bool wide_digits = false; // some column has c > 16: the digits of the launch are 32-bit words
   u32 segment_log2 = kSegmentLog2;               // sorted entries per k_accumulate lane
-  u32 reduce_segment_log2 = kReduceSegmentLog2; // buckets per k_reduce lane (a block: 256 lanes)
-  u32 reduce_block_buckets() const { return kReduceThreads << reduce_segment_log2; }
+  u32 reduce_segment_log2 = kReduceSegmentLog2; // buckets per k_reduce lane
+  u32 reduce_threads = kReduceThreads;          // lanes of a k_reduce block: 256, or 64 (small tasks)
+  u32 reduce_block_buckets() const { return reduce_threads << reduce_segment_log2; }
+  // the same block size as k_horner takes it: log2(buckets per block / 256)
+  u32 reduce_block_log2_over_256() const {
+    return reduce_threads == 64 ? reduce_segment_log2 - 2 : reduce_segment_log2;
+  }
 };
 
 #ifndef BZ_THROUGHPUT_BUCKET_COST
@@ -422,6 +427,13 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
                                        tune.in_sequence && plan.total_entries >= (u64{1} << 23),
                                        !tune.in_sequence && nonempty < tune.throughput_columns,
                                        nonempty >= tune.throughput_columns);
+  // many small tasks: one wavefront per block (kernels.h, k_reduce<.., 64>); the block still covers a
+  // multiple of 256 buckets (s >= 2), which is the unit k_horner counts a task's partials in
+  if (tune.force_reduce_segment_log2 == 0 && nonempty >= tune.throughput_columns &&
+      plan.reduce_segment_log2 >= 2 &&
+      (u64{64} << plan.reduce_segment_log2) >= plan.max_task_buckets) {
+    plan.reduce_threads = 64;
+  }
   return plan;
 }
 

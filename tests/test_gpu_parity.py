@@ -270,6 +270,25 @@ def test_row_sharded_fold_on_device(gpu_backend, oracle):
         _ = ctypes
 
 
+def test_many_short_columns(gpu_backend, oracle):
+    """the reference's bucket_method2 regime (sxt/multiexp/bucket_method2/multiexponentiation.h:48-121:
+    256 <= n <= 4096, many outputs): the planner gives such launches 32 or fewer entries per
+    accumulation lane, tasks of 256 buckets and k_reduce blocks of ONE wavefront (64 lanes x 4
+    buckets, scan and tree over the lanes in use); one launch also mixes a few much shorter columns
+    in, whose tasks use a fraction of the lanes"""
+    api = gpu_backend
+    rng = np.random.default_rng(4096)
+    for curve_id, n, columns in ((0, 4096, 12), (2, 4096, 8), (3, 1024, 9), (1, 2048, 6)):
+        gens = util.generators_for(curve_id, n)
+        g = util.api_generators(curve_id, gens)
+        cols = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False) for _ in range(columns)]
+        cols += [(rng.integers(0, 256, (300, 32), dtype=np.uint8), False),
+                 (rng.integers(0, 256, (n - 1, 16), dtype=np.uint8), False),
+                 (rng.integers(0, 256, (1, 32), dtype=np.uint8), False)]
+        got = api.compute_pedersen_commitments(curve_id, cols, generators=g)
+        assert np.array_equal(got, oracle.commit(curve_id, cols, gens)), curve_id
+
+
 def test_skewed_and_batched_columns(gpu_backend, oracle):
     """digit distributions that put most entries in one bucket (equal scalars, two values, all
     ones, sparse) and many-column jobs split into several batches by the engine; results never
