@@ -738,7 +738,7 @@ def device_state(lib, sequence_call, lone_call, stream, trace):
     return out
 
 
-def host_api():
+def host_api(oracle=None, generators=None):
     """What a drop-in caller sees: the blocking sxt_* entry points with HOST buffers, PCIe-inclusive,
     in child processes (their own sxt_init, no torch): the native warm driver
     (tools/pipeline_bench/hostapi_bench.cc) and the clone of the reference's own benchmark CLI
@@ -758,21 +758,56 @@ def host_api():
     except Exception as exc:  # a failure here must not cost the bench line
         out["warm"] = {"error": repr(exc)[:300]}
     cli = os.path.join(ROOT, "tools", "multi_commitment", "_build", "multi_commitment")
-    out["reference_cli_clone"] = []
-    for columns in (1, 10):
-        entry = {"command": f"multi_commitment gpu 1048576 10 {columns} 32 0"}
+
+    def run_cli(n, columns, nbytes):
+        entry = {"command": f"multi_commitment gpu {n} 10 {columns} {nbytes} 0"}
         try:
-            r = subprocess.run([cli, "gpu", "1048576", "10", str(columns), "32", "0"],
-                               capture_output=True, text=True, timeout=300)
+            r = subprocess.run([cli, "gpu", str(n), "10", str(columns), str(nbytes), "0"],
+                               capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, BLITZAR_AMD_CLI_WARM="1"))
             for ln in r.stdout.splitlines():
                 if ln.startswith("compute duration (s)"):
                     entry["mean_ms_incl_cold_first_sample"] = 1e3 * float(ln.split(":")[1])
+                if ln.startswith("warm compute duration (s)"):
+                    entry["warm_mean_ms"] = 1e3 * float(ln.split(":")[1])
                 if ln.startswith("throughput (exponentiations / s)"):
                     entry["exponentiations_per_s"] = float(ln.split(":")[1])
+            if "warm_mean_ms" in entry:
+                entry["exponentiations_per_s_warm"] = n * columns / (entry["warm_mean_ms"] * 1e-3)
             entry["rc"] = r.returncode
         except Exception as exc:
             entry["error"] = repr(exc)[:300]
-        out["reference_cli_clone"].append(entry)
+        return entry
+
+    out["reference_cli_clone"] = [run_cli(1048576, columns, 32) for columns in (1, 10)]
+    # the reference's own benchmark grid (benchmark/scripts/run_benchmarks.py:24-39): n x commitments x
+    # element bytes, 10 samples each, through the same CLI clone; beside every (n, bytes) the reference
+    # CPU backend on ONE column of that shape (columns are independent)
+    grid = []
+    cpu = {}
+    for columns in (1, 10):
+        for nbytes in (1, 32):
+            for n in (10000, 100000, 1000000):
+                e = run_cli(n, columns, nbytes)
+                if oracle is not None and (n < 1000000 or nbytes == 1):
+                    if (n, nbytes) not in cpu:
+                        rng = np.random.default_rng(n + nbytes)
+                        col = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
+                        if nbytes == 32:
+                            col[:, 31] &= 0x0f
+                        gens = (generators[:n] if generators is not None and len(generators) >= n
+                                else oracle.ristretto_generators(n))
+                        t0 = time.perf_counter()
+                        oracle.commit(0, [(col, False)], gens)
+                        cpu[(n, nbytes)] = n / (time.perf_counter() - t0)
+                    e["reference_cpu_ops_per_s_1_core"] = cpu[(n, nbytes)]
+                grid.append(e)
+    out["reference_benchmark_grid"] = grid
+    out["reference_benchmark_grid_note"] = (
+        "run_benchmarks.py's sweep: n in {1e4, 1e5, 1e6} x {1, 10} commitments x {1, 32} bytes; host "
+        "buffers, caller generators uploaded per call; `warm_mean_ms` leaves the first sample out "
+        "(BLITZAR_AMD_CLI_WARM, an extension of the clone); the reference CPU rate of 1e6 x 32 bytes is "
+        "the headline's own cpu_baseline")
     return out
 
 
@@ -1057,8 +1092,10 @@ def main():
     # CPU baseline
     cpu = None
     verified = None
+    headline_gens = None
     if oracle is not None and not args.skip_headline_check:
         gens_host = oracle.ristretto_generators(n)
+        headline_gens = gens_host
         t2 = time.perf_counter()
         want = oracle.commit(0, [(scalars_host, False)], gens_host)
         cdt = time.perf_counter() - t2
@@ -1191,7 +1228,7 @@ def main():
         if not args.no_configs and not args.dry_run_one_gpu and torch.cuda.device_count() > 1:
             result["in_process_multi_device"] = in_process_multi_device()
         if world == 1 and not args.no_configs and args.log2n is None and not args.no_aux:
-            result["host_api"] = host_api()
+            result["host_api"] = host_api(oracle, headline_gens)
         print(json.dumps(result), flush=True)
 
 

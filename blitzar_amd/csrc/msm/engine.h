@@ -410,6 +410,30 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
     msm_plan plan = plan_range(begin, end, bytes);
     if (!fits(plan, bytes) && end - begin > 1) {
       size_t lo = begin + 1, hi = end; // [begin, lo) is accepted, [begin, hi) is known not to fit
+      // Columns of one call mostly share a shape: try the prefix the limits allow in proportion
+      // first (3 % short of it) and take it if it fits -- a planning pass over a thousand columns
+      // costs ~0.5 ms of host time, and ten of them per call made launches of 1024 short columns
+      // host-bound (7-11 ms of enqueueing for 4 ms of device work).
+      {
+        const double by_tasks = static_cast<double>(tune.max_tasks_per_batch) /
+                                static_cast<double>(plan.tasks.size() ? plan.tasks.size() : 1);
+        const double by_bytes = static_cast<double>(tune.max_workspace_bytes) /
+                                static_cast<double>(bytes ? bytes : 1);
+        const double share = 0.97 * (by_tasks < by_bytes ? by_tasks : by_bytes);
+        const size_t guess = begin + static_cast<size_t>(static_cast<double>(end - begin) * share);
+        if (guess > begin + 1 && guess < end) {
+          size_t guess_bytes = 0;
+          msm_plan p = plan_range(begin, guess, guess_bytes);
+          if (fits(p, guess_bytes)) {
+            if (guess_bytes > need) need = guess_bytes;
+            first_column.push_back(begin);
+            batches.push_back(std::move(p));
+            begin = guess;
+            continue;
+          }
+          hi = guess;
+        }
+      }
       plan = plan_range(begin, lo, bytes);
       while (hi - lo > 1) {
         const size_t mid = lo + (hi - lo) / 2;

@@ -196,7 +196,7 @@ struct msm_plan {
 struct msm_tuning {
   u32 max_window_bits = 16; // digits are stored as int16
   // batching of many-column jobs: tasks per launch (grid.y) and device workspace per batch
-  size_t max_tasks_per_batch = 32768;
+  size_t max_tasks_per_batch = 65000; // (tasks + 1 is a launch-grid dimension: at most 65535)
   size_t max_workspace_bytes = size_t{64} << 30;
   // two-pass sort geometry (choose_partition below): entries per bucket group
   u32 partition_group_entries = kGroupTargetEntries;
