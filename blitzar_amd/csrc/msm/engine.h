@@ -575,7 +575,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                        out_stride, projective_out ? 1 : 0, static_cast<point*>(nullptr),
                        static_cast<const point*>(nullptr), 1u, b.cols,
                        static_cast<const task_desc*>(nullptr), static_cast<const u32*>(nullptr), 0u,
-                       0u, 1, 1, plan.reduce_block_log2_over_256());
+                       0u, 1, 1, plan.reduce_block_log2());
     g_kernel_launches += 1;
     BZ_HIP_CHECK(hipGetLastError());
     if (mode.piped) {
@@ -792,7 +792,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
                        b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,
-                       plan.reduce_block_log2_over_256());
+                       plan.reduce_block_log2());
   });
   if (mode.piped) {
     ctx.horner_done[k & 3].record(hs);

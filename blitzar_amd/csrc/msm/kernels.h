@@ -1854,7 +1854,7 @@ __global__ void __launch_bounds__(kCombineThreads)
              typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
              u32 partial_stride, const column_desc* __restrict__ columns,
              const task_desc* __restrict__ tasks, const u32* __restrict__ task_total, u32 w_lo_arg,
-             u32 w_hi_arg, int first, int last, u32 reduce_seg_log2) {
+             u32 w_hi_arg, int first, int last, u32 reduce_block_log2) {
   using point = typename C::point;
   __shared__ point tree[kCombineThreads];
   __builtin_amdgcn_s_setprio(BZ_HORNER_PRIO); // one workgroup per column, possibly beside k_accumulate
@@ -1893,7 +1893,7 @@ __global__ void __launch_bounds__(kCombineThreads)
   const u32 w = tid / team;
   const u32 lane = tid % team;
   const u32 nb = 1u << (col.window_bits - 1);
-  const u32 reduce_block = kReduceThreads << reduce_seg_log2; // buckets per k_reduce block
+  const u32 reduce_block = 1u << reduce_block_log2; // buckets per k_reduce block (lanes x 2^s)
   const u32 blocks = (nb + reduce_block - 1) / reduce_block;
   point sum = C::identity();
   if (w < W && lane < blocks) {

@@ -184,10 +184,8 @@ struct msm_plan {
   u32 reduce_segment_log2 = kReduceSegmentLog2; // buckets per k_reduce lane
   u32 reduce_threads = kReduceThreads;          // lanes of a k_reduce block: 256, or 64 (small tasks)
   u32 reduce_block_buckets() const { return reduce_threads << reduce_segment_log2; }
-  // the same block size as k_horner takes it: log2(buckets per block / 256)
-  u32 reduce_block_log2_over_256() const {
-    return reduce_threads == 64 ? reduce_segment_log2 - 2 : reduce_segment_log2;
-  }
+  // log2 of the buckets a k_reduce block covers (what k_horner counts a task's partials by)
+  u32 reduce_block_log2() const { return (reduce_threads == 64 ? 6 : 8) + reduce_segment_log2; }
 };
 
 #ifndef BZ_THROUGHPUT_BUCKET_COST
@@ -427,10 +425,8 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
                                        tune.in_sequence && plan.total_entries >= (u64{1} << 23),
                                        !tune.in_sequence && nonempty < tune.throughput_columns,
                                        nonempty >= tune.throughput_columns);
-  // many small tasks: one wavefront per block (kernels.h, k_reduce<.., 64>); the block still covers a
-  // multiple of 256 buckets (s >= 2), which is the unit k_horner counts a task's partials in
+  // many small tasks: one wavefront per block (kernels.h, k_reduce<.., 64>)
   if (tune.force_reduce_segment_log2 == 0 && nonempty >= tune.throughput_columns &&
-      plan.reduce_segment_log2 >= 2 &&
       (u64{64} << plan.reduce_segment_log2) >= plan.max_task_buckets) {
     plan.reduce_threads = 64;
   }

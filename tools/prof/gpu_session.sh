@@ -7,8 +7,8 @@
 #   tests:<k>   the same with -k <k>
 #   bench       python bench.py (the driver's default line)            -> bench.json
 #   bench-quick python bench.py --no-configs --skip-headline-check     -> bench_quick.json
-#   stats       rocprofv3 --kernel-trace --stats of bench.py --no-aux  -> prof_stats/
-#   pmc         three --pmc passes (SQ_*, FETCH_SIZE, WRITE_SIZE) of bench.py --no-aux, no tracing
+#   profile     tools/prof/run_pmc_configs.sh: rocprofv3 --kernel-trace --stats + three --pmc passes
+#               (SQ_*, FETCH_SIZE, WRITE_SIZE; no tracing beside counters) -> gpurun_out/prof_<tag>/
 #   ab:<spec-file>   tools/prof/ab_pipeline.sh over the lines of <spec-file> ("<bench args> -- <specs>")
 #   grid        the reference's benchmark grid + the short-column / many-column regime -> grid.json
 #   cmd:<file>  bash <file> (a one-off, kept under gpurun_out/)
@@ -35,20 +35,10 @@ for step in "$@"; do
     bench-quick)
       timeout 600 python bench.py --no-configs --skip-headline-check > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
       echo "rc=$?" | tee -a "$OUT/session.log" ;;
-    stats)
-      (cd /tmp && timeout -k 10 420 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof_stats" -- \
-        python "$OLDPWD/bench.py" --no-aux --skip-headline-check > "$OLDPWD/$OUT/stats_bench.json" 2> "$OLDPWD/$OUT/stats.err")
-      find "$OUT/prof_stats" -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
-      echo "rc=$?" | tee -a "$OUT/session.log" ;;
-    pmc)
-      for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
-                 "FETCH_SIZE" "WRITE_SIZE"; do
-        name=$(echo $set | cut -d' ' -f1)
-        (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $set -d "$OLDPWD/$OUT/pmc_$name" -- \
-          python "$OLDPWD/bench.py" --no-aux --skip-headline-check --steps 5 --config-steps 1 \
-          > "$OLDPWD/$OUT/pmc_$name.json" 2> "$OLDPWD/$OUT/pmc_$name.err")
-        echo "pmc $name rc=$?" | tee -a "$OUT/session.log"
-      done ;;
+    profile)
+      # rocprofv3 --kernel-trace --stats + three --pmc passes of bench.py with its configs legs
+      bash tools/prof/run_pmc_configs.sh "$TAG" > "$OUT/profile.log" 2>&1
+      echo "rc=$?" | tee -a "$OUT/session.log"; grep "rc=" "$OUT/profile.log" | tee -a "$OUT/session.log" ;;
     ab:*)
       while IFS= read -r line; do
         [ -z "$line" ] && continue

@@ -17,13 +17,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --config-steps 1 --skip-headline-check --no-aux $*"
 TRACE_ARGS="--steps 20 --warmup 5 --config-steps 3 --skip-headline-check --no-aux $*"
-timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- python "$REPO/bench.py" $TRACE_ARGS > "$OUT/trace.log" 2>&1
+timeout -k 10 330 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- python "$REPO/bench.py" $TRACE_ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
-timeout 420 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_IFETCH SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -o r -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_sq.log" 2>&1
+timeout -k 10 330 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_IFETCH SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -o r -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"
-timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o r -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
+timeout -k 10 330 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o r -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc_fetch rc=$?"
-timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o r -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
+timeout -k 10 330 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o r -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 echo "pmc_write rc=$?"
 cd "$REPO"
 # keep what travels back small: the per-dispatch counter csv and the stats, not the kernel traces
