@@ -363,13 +363,7 @@ row_pipeline_shape choose_row_chunks(const curve_vtable& vt, const std::vector<h
   // what they cost (8 chunks: 1.78 -> 2.96 ms).
   (void)vt;
   if (!uploads_generators || longest < (u64{1} << 19)) return {1, 0};
-  // BLITZAR_AMD_ROW_PIPELINE_LEAD: the number of lead columns (A/B runs)
-  static const u32 lead_columns = [] {
-    const char* e = std::getenv("BLITZAR_AMD_ROW_PIPELINE_LEAD");
-    const long v = e != nullptr ? std::atol(e) : 0;
-    return v >= 1 && v <= 64 ? static_cast<u32>(v) : 4u;
-  }();
-  return {8, std::min(lead_columns, num_cols)};
+  return {8, std::min(4u, num_cols)};
 }
 
 // The same commitments as enqueue_commitments, as a pipeline over `chunks` row ranges for the first

@@ -154,22 +154,10 @@ bool msm_probe_mad_rate(double target_ms, double out[4]) {
 
 msm_context* msm_context_new() {
   auto* ctx = new msm_context();
-  // development overrides of the sort geometry (plan.h), validated like bzamd_set_tuning: a window
-  // width above 16 would overflow the int16 digit storage, one below 2 gives more windows than
-  // k_horner's 256 lanes can fold
-  if (const char* v = std::getenv("BLITZAR_AMD_GROUP_ENTRIES")) {
-    const unsigned long e = std::strtoul(v, nullptr, 10);
-    BZ_RELEASE_ASSERT(e >= 64 && e <= kLocalSortCapacity,
-                      "BLITZAR_AMD_GROUP_ENTRIES must be in [64, 6144]");
-    ctx->tuning.partition_group_entries = static_cast<u32>(e);
-  }
+  // development overrides of the launch geometry (plan.h) for A/B runs through the native drivers;
+  // the same values as bzamd_set_tuning / bzamd_set_segments, validated there
   if (const char* v = std::getenv("BLITZAR_AMD_MAX_WINDOW_BITS")) {
     msm_context_set_tuning(ctx, static_cast<u32>(std::strtoul(v, nullptr, 10)), 0, 0);
-  }
-  if (const char* v = std::getenv("BLITZAR_AMD_BUCKET_COST")) {
-    const double cost = std::strtod(v, nullptr);
-    BZ_RELEASE_ASSERT(cost > 0 && cost < 1e6, "BLITZAR_AMD_BUCKET_COST must be positive");
-    ctx->tuning.throughput_bucket_cost = cost;
   }
   if (const char* v = std::getenv("BLITZAR_AMD_REDUCE_SEGMENT_LOG2")) {
     msm_context_set_segments(ctx, ctx->tuning.force_segment_log2,

@@ -1,5 +1,5 @@
 """Device-resident curve25519 calls of k columns x 2^20 rows in throughput mode: ms per call of a
-sequence (bzamd_pipeline_next) against lone calls; BLITZAR_AMD_DEFER_COLUMNS moves the column count
+sequence (bzamd_pipeline_next) against lone calls; msm_tuning::defer_max_columns (64) is the column count
 from which the engine ignores the request."""
 import ctypes
 import sys
