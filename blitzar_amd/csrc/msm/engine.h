@@ -182,27 +182,29 @@ struct msm_context {
   // BLITZAR_AMD_COMPACT_REDUCE: 0 never, 1 always, 2 (default) where the probe and the launch say so
   u32 compact_reduce = 2;
   bool slow_instruction_fetch = false;
-  // compute units a launch on `stream` may use (a caller's stream may carry a CU mask); queried once
-  // per stream handle.  k_group_sort_all's workers must all be resident at once.
-  hipStream_t cus_of_stream = nullptr;
-  u32 cus_available = 0;
+  // compute units a launch on `stream` may use (a caller's stream may carry a CU mask).
+  // k_group_sort_all's workers must all be resident at once.  Asked on every call -- a getter on the
+  // stream object; a handle value can come back for a different stream, so nothing is cached per handle.
+  u32 device_cus = 0;
   u32 stream_cus(hipStream_t stream) {
-    if (cus_available != 0 && stream == cus_of_stream) return cus_available;
-    int device = 0, cus = 0;
-    BZ_HIP_CHECK(hipGetDevice(&device));
-    BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    u32 usable = static_cast<u32>(cus);
-    uint32_t mask[32] = {};
-    if (stream != nullptr && hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
-      u32 bits = 0;
-      for (u32 w = 0; w < 32; ++w) bits += static_cast<u32>(__builtin_popcount(mask[w]));
-      if (bits != 0 && bits < usable) usable = bits;
-    } else {
-      (void)hipGetLastError();
+    if (device_cus == 0) {
+      int device = 0, cus = 0;
+      BZ_HIP_CHECK(hipGetDevice(&device));
+      BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+      device_cus = cus > 0 ? static_cast<u32>(cus) : 1;
     }
-    cus_of_stream = stream;
-    cus_available = usable == 0 ? 1 : usable;
-    return cus_available;
+    u32 usable = device_cus;
+    if (stream != nullptr) {
+      uint32_t mask[32] = {};
+      if (hipExtStreamGetCUMask(stream, 32, mask) == hipSuccess) {
+        u32 bits = 0;
+        for (u32 w = 0; w < 32; ++w) bits += static_cast<u32>(__builtin_popcount(mask[w]));
+        if (bits != 0 && bits < usable) usable = bits;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    return usable;
   }
   void make_pipe_streams() {
     if (tail != nullptr) return;

@@ -37,15 +37,15 @@ constexpr u32 kSegmentLog2Max = 7;
 constexpr u64 kSegmentFillLanes = u64{1} << 19;
 constexpr u32 kSegmentEntries = 1u << kSegmentLog2;
 constexpr u32 kSegmentLog2Min = 3;
-// `mean_task_rows`: a task's lanes are rows / 2^s of ONE workgroup row of k_accumulate's grid, so short
+// `task_rows` (of a typical entry's task): a task's lanes are rows / 2^s of ONE workgroup row of k_accumulate's grid, so short
 // tasks must keep s small enough for whole wavefronts: 1024 columns x 4096 rows (the reference's
 // bucket_method2 regime) chose 128 entries per lane from its 1.2e8 entries and ran every task on HALF
 // a wavefront -- k_accumulate 10.8 ms against 5.7 ms at 32 entries per lane
 // (profiles/round5_ab_wide_tables_and_short_columns.log).  At least 128 lanes per task where the rows allow it.
-inline u32 choose_segment_log2(u64 total_entries, u64 mean_task_rows = ~u64{0}) {
+inline u32 choose_segment_log2(u64 total_entries, u64 task_rows = ~u64{0}) {
   u32 s = kSegmentLog2;
   while (s < kSegmentLog2Max && (total_entries >> (s + 1)) >= kSegmentFillLanes) ++s;
-  while (s > kSegmentLog2Min && (mean_task_rows >> s) < 128) --s;
+  while (s > kSegmentLog2Min && (task_rows >> s) < 128) --s;
   return s;
 }
 constexpr u32 kStagedSliceRows = 1u << 14; // rows per partition workgroup: staged in LDS / direct
@@ -342,17 +342,23 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     return sh;
   };
   // entries per accumulation lane: one value for the launch, from its total number of entries
-  u64 launch_entries = 0, launch_tasks = 0;
+  // ... and from the rows of the task a typical ENTRY lives in (the entry-weighted mean of the tasks'
+  // rows: one long column among a thousand short ones keeps its own geometry)
+  u64 launch_entries = 0;
+  double rows_squared = 0;
   for (const auto& hc : cols) {
     if (hc.n == 0) continue;
     const column_shape sh = shape_of(hc);
-    launch_entries += sh.task_rows * (sh.merged ? 1 : sh.w);
-    launch_tasks += sh.merged ? 1 : sh.w;
+    const u64 tasks = sh.merged ? 1 : sh.w;
+    launch_entries += sh.task_rows * tasks;
+    rows_squared += static_cast<double>(sh.task_rows) * static_cast<double>(sh.task_rows) *
+                    static_cast<double>(tasks);
   }
-  plan.segment_log2 =
-      tune.force_segment_log2 != 0
-          ? tune.force_segment_log2
-          : choose_segment_log2(launch_entries, launch_tasks != 0 ? launch_entries / launch_tasks : 0);
+  const u64 typical_task_rows =
+      launch_entries != 0 ? static_cast<u64>(rows_squared / static_cast<double>(launch_entries)) : 0;
+  plan.segment_log2 = tune.force_segment_log2 != 0
+                          ? tune.force_segment_log2
+                          : choose_segment_log2(launch_entries, typical_task_rows);
   const u64 seg_entries = u64{1} << plan.segment_log2;
   for (size_t ci = 0; ci < cols.size(); ++ci) {
     const host_column& hc = cols[ci];

@@ -224,6 +224,10 @@ def test_planner_invariants():
     assert per[0][0] == 9 and totals[6:].tolist() == [5, 2]
     _, totals = hooks.plan([1024] * 1024, [256] * 1024, [0] * 1024)
     assert totals[6] == 3
+    # ... by the task a typical ENTRY lives in: one 2^22-row column among 200 columns of 256 rows keeps
+    # the long column's geometry (its 17 tasks hold 99.9 % of the entries)
+    _, totals = hooks.plan([1 << 22] + [256] * 200, [256] * 201, [0] * 201)
+    assert totals[6] >= 5
     # blocks of the bucket reduction stay full: 2^13 buckets per task leave 32 per lane
     per, totals = hooks.plan([1 << 20] * 256, [256] * 256, [0] * 256, max_window_bits=14)
     assert per[0][0] == 14 and totals[6:].tolist() == [7, 5]
