@@ -15,7 +15,10 @@ commitments -- weak scaling.
 
 Prints ONE JSON line (rank 0): metric = scalar-point ops / s over the whole job.  Extra members:
   roofline      dominant kernel k_accumulate: algorithmic bytes per launch / its HIP-event duration
-                against 8 TB/s, plus the integer-ALU side (the binding bound)
+                against 8 TB/s, plus the integer-ALU side (the binding bound) normalised to the
+                v_mad_u64_u32 issue rate measured on THIS box in THIS run, and `box`: which box ran
+                (serial, fetch kind, shader clock and socket power under the sustained leg from a
+                50 Hz amdsmi trace) -- every such figure also as a flat scalar of `roofline`
   cpu_baseline  N = 1 only: the reference's own CPU backend (oracle/_ref) on THE SAME scalars; the
                 timed GPU commitment must equal its output or the bench aborts (`verified`)
   configs       N = 1: BASELINE configs 1, 3, 4, 5 at their stated shapes on one GPU, each with
@@ -1229,6 +1232,21 @@ def main():
             result["in_process_multi_device"] = in_process_multi_device()
         if world == 1 and not args.no_configs and args.log2n is None and not args.no_aux:
             result["host_api"] = host_api(oracle, headline_gens)
+        # last member of the line (logs that keep only its tail still get the essentials): the step,
+        # the dominant kernel, which box ran and at what clocks / power, the other configs
+        roof = result.get("roofline", {})
+        summary = {"ms_per_step": result["ms_per_step"], "ops_per_s": result["value"],
+                   "k_accumulate_ms": roof.get("kernel_ms"), "hbm_frac": roof.get("frac"),
+                   "alu_frac_in_run": roof.get("alu_frac"), "verified": bool(result.get("verified")),
+                   "box": {k[4:]: roof[k] for k in roof if k.startswith("box_")}}
+        if "configs" in result:
+            summary["configs_ms_per_call"] = {c["config"].split(":")[0]: round(c["ms_per_call"], 3)
+                                              for c in result["configs"] if "ms_per_call" in c}
+        warm = result.get("host_api", {}).get("warm", {}).get("cases")
+        if warm:
+            summary["host_api_ms"] = {f"{c['columns']}col_{c['generators'].split()[0]}": c["ms_mean"]
+                                      for c in warm}
+        result["summary"] = summary
         print(json.dumps(result), flush=True)
 
 
