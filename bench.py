@@ -852,6 +852,10 @@ def box_record(roof, state, legs, lone_call_ms, lib):
         roof["box_power_w_max"] = seq["socket_power_w"]["max"]
     if seq.get("energy_counter_mean_w") is not None:
         roof["box_power_w_energy_counter"] = seq["energy_counter_mean_w"]
+    for name in ("uclk_mhz", "socclk_mhz", "socclks_mhz_mean"):
+        if seq.get(name) is not None:
+            box[name + "_under_sequence"] = seq[name]
+            roof["box_" + name + "_under_sequence"] = seq[name]
     if isinstance(lone.get("socket_power_w"), dict):
         roof["box_power_w_lone_calls_mean"] = lone["socket_power_w"]["mean"]
     roof["box_trace_hz"] = seq.get("hz")

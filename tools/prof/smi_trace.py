@@ -64,6 +64,17 @@ def sample(amdsmi, h):
     clks = m.get("current_gfxclks")
     if isinstance(clks, (list, tuple)):
         s["gfxclks"] = [c for c in clks if _num(c) is not None]
+    # memory and fabric-side clocks: the two kinds of boxes in the pool differ on everything that goes
+    # through the L2 / fabric (instruction fetch beyond the I-cache, the memory-bound front kernels)
+    for k in ("current_uclk", "current_socclk"):
+        v = _num(m.get(k))
+        if v is not None:
+            s[k] = v
+    socs = m.get("current_socclks")
+    if isinstance(socs, (list, tuple)):
+        socs = [c for c in socs if _num(c) is not None]
+        if socs:
+            s["socclks"] = socs
     return s
 
 
@@ -137,6 +148,13 @@ def summarize(samples, t0, t1):
     clk = [c for s in win for c in s.get("gfxclks", [])]
     if clk:
         out["sclk_mhz"] = {"min": min(clk), "mean": round(sum(clk) / len(clk), 1), "max": max(clk)}
+    for key, name in (("current_uclk", "uclk_mhz"), ("current_socclk", "socclk_mhz")):
+        v = [s[key] for s in win if key in s]
+        if v:
+            out[name] = round(sum(v) / len(v), 1)
+    soc = [c for s in win for c in s.get("socclks", [])]
+    if soc:
+        out["socclks_mhz_mean"] = round(sum(soc) / len(soc), 1)
     e = [(s["t"], s["energy_accumulator"]) for s in win if "energy_accumulator" in s]
     if len(e) >= 2 and e[-1][0] > e[0][0] and e[-1][1] > e[0][1]:
         out["energy_counter_mean_w"] = round(
