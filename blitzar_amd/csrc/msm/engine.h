@@ -676,6 +676,9 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // workgroup are most of the sort (2^16 rows: 0.090 ms): chunks over the workers instead.
   const u32 stream_limit =
       plan.total_entries <= (u64{1} << 22) ? kLocalSortCapacity : kStreamedSortRecords;
+  // every task is ONE bucket group of at most an LDS stage's worth of rows (hundreds of short columns):
+  // k_task_sort does the whole sort of a task in one workgroup, one launch instead of three
+  const bool small_tasks = plan.max_task_groups == 1 && plan.max_task_rows <= kLocalSortCapacity;
   // the kernels that write / read the stored digits, for the launch's digit type
   auto recode_and_partition = [&](auto digit_tag) {
     using D = decltype(digit_tag);
@@ -704,6 +707,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                          b.tasks, num_cols, chunks, b.group_cursor, zero_words);
     });
     ctx.timer.timed(timing, 2, fs, [&] {
+      if (small_tasks) {
+        hipLaunchKernelGGL((k_task_sort<D>), dim3(num_tasks), dim3(kGroupSortThreads), 0, fs, b.sorted,
+                           b.segment_bucket, b.bucket_end, digits, b.tasks);
+        return;
+      }
       u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
       // pass 1a (+ 1b in the last workgroup of every task)
       hipLaunchKernelGGL((k_group_hist<D>), dim3(plan.max_task_slices, num_tasks), dim3(kSortThreads),
@@ -727,19 +735,20 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   } else {
     recode_and_partition(i16{});
   }
-  u32 sort_launches = 0;
-  ctx.timer.timed(timing, 2, fs, [&] {
-    u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
-    // pass 2, the oversized groups (skewed digits) in one more row of the same grid: their workers
-    // meet at a barrier, so there may only be as many as the stream's compute units hold at once
-    const u32 cus = ctx.stream_cus(fs);
-    const u32 workers = 2 * cus < kBigSortBlocks ? 2 * cus : kBigSortBlocks;
-    hipLaunchKernelGGL(k_group_sort_all, dim3(plan.max_task_groups, num_tasks + 1),
-                       dim3(kGroupSortThreads), 0, fs, b.sorted, b.segment_bucket, b.bucket_end,
-                       b.records, b.group_start, b.group_chunk, b.tasks, num_tasks, b.bucket_count,
-                       bucket_fill, b.big_tasks, b.big_barrier, workers);
-    sort_launches = 3;
-  });
+  const u32 sort_launches = small_tasks ? 1 : 3;
+  if (!small_tasks) {
+    ctx.timer.timed(timing, 2, fs, [&] {
+      u32* bucket_fill = b.bucket_count + plan.total_buckets + 1;
+      // pass 2, the oversized groups (skewed digits) in one more row of the same grid: their workers
+      // meet at a barrier, so there may only be as many as the stream's compute units hold at once
+      const u32 cus = ctx.stream_cus(fs);
+      const u32 workers = 2 * cus < kBigSortBlocks ? 2 * cus : kBigSortBlocks;
+      hipLaunchKernelGGL(k_group_sort_all, dim3(plan.max_task_groups, num_tasks + 1),
+                         dim3(kGroupSortThreads), 0, fs, b.sorted, b.segment_bucket, b.bucket_end,
+                         b.records, b.group_start, b.group_chunk, b.tasks, num_tasks, b.bucket_count,
+                         bucket_fill, b.big_tasks, b.big_barrier, workers);
+    });
+  }
 
   // ---- accumulate: rewrites the bucket sums / head partials the reduce two batches ago read
   wait_for(earlier(ctx.reduce_done, 2), as);

@@ -1127,6 +1127,92 @@ big_sort_body(u32 worker, u32 workers, u32* __restrict__ sorted, u32* __restrict
   }
 }
 
+// The whole sort of a SMALL task in one workgroup (launches whose every task has ONE bucket group and
+// at most kLocalSortCapacity rows: hundreds of short columns, the reference's bucket_method2 regime).
+// For such a task pass 1 only turned digits into records of the one group; here the workgroup reads
+// the task's digits, counting-sorts them by bucket in LDS and writes the sorted entries, the bucket
+// ends and the segment -> bucket map -- one launch instead of three, two passes over the digits less
+// (1024 columns x 4096 rows: the sort 1.5 ms of a 9.8 ms call).
+template <class D>
+__global__ void __launch_bounds__(kGroupSortThreads, 8)
+    k_task_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
+                u32* __restrict__ bucket_end, const D* __restrict__ digits,
+                const task_desc* __restrict__ tasks) {
+  __shared__ sort_lds lds;
+  u32* cursor = lds.cursor;
+  u32* staging = lds.staging;
+  u32* wave_sums = lds.wave_sums;
+  const task_desc task = tasks[blockIdx.x];
+  const u32 buckets = task.num_buckets; // <= 2^kMaxGroupBits: the task is one group
+  const u32 rows = static_cast<u32>(task.rows); // <= kLocalSortCapacity
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (u32 b = tid; b < buckets; b += kGroupSortThreads) cursor[b] = 0;
+  lds_barrier();
+  const D* dig = digits + task.entry_base;
+  // sign << 31 | bucket << 13 | row (row < 6144 < 2^13, bucket < 2^10); 0 = a zero digit
+  u32 mine[kLocalSortPerThread];
+  u32 rank2[(kLocalSortPerThread + 1) / 2];
+#pragma unroll
+  for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+    const u32 i = tid + k * kGroupSortThreads;
+    const int e = i < rows ? static_cast<int>(dig[i]) : 0;
+    const u32 mag = e < 0 ? static_cast<u32>(-e) : static_cast<u32>(e);
+    // E = -D: positive E means the digit is negative -> subtract the generator
+    mine[k] = e == 0 ? 0u : ((e > 0 ? 0x80000000u : 0u) | ((mag - 1) << 13) | i | 0x40000000u);
+    u32 r = 0;
+    if (e != 0) r = atomicAdd(&cursor[mag - 1], 1u);
+    if ((k & 1) == 0) {
+      rank2[k / 2] = r;
+    } else {
+      rank2[k / 2] |= r << 16;
+    }
+  }
+  lds_barrier();
+  // exclusive scan of the bucket counts, two adjacent buckets per lane (as group_sort_block)
+  const u32 b0 = 2 * tid;
+  const u32 c0 = b0 < buckets ? cursor[b0] : 0, c1 = b0 + 1 < buckets ? cursor[b0 + 1] : 0;
+  const u32 local = c0 + c1;
+  u32 incl = local;
+#pragma unroll
+  for (u32 off = 1; off < 64; off <<= 1) {
+    const u32 up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  lds_barrier();
+  u32 start0 = incl - local;
+  u32 total = 0;
+  for (u32 w = 0; w < kGroupSortThreads / 64; ++w) {
+    if (w < wave) start0 += wave_sums[w];
+    total += wave_sums[w];
+  }
+  const u32 start1 = start0 + c0;
+  u32* ends = bucket_end + task.bucket_base;
+  if (b0 < buckets) {
+    cursor[b0] = start0;
+    ends[b0] = start0 + c0;
+  }
+  if (b0 + 1 < buckets) {
+    cursor[b0 + 1] = start1;
+    ends[b0 + 1] = start1 + c1;
+  }
+  lds_barrier();
+  u32* seg = segment_bucket + task.segment_base;
+  const u32 seg_log2 = task.segment_log2, seg_mask = (1u << seg_log2) - 1;
+#pragma unroll
+  for (u32 k = 0; k < kLocalSortPerThread; ++k) {
+    if (mine[k] != 0) {
+      const u32 b = (mine[k] >> 13) & 0x3ffu;
+      const u32 at = cursor[b] + ((rank2[k / 2] >> (16 * (k & 1))) & 0xffffu);
+      staging[at] = (mine[k] & 0x80000000u) | (mine[k] & 0x1fffu);
+      if ((at & seg_mask) == 0) seg[at >> seg_log2] = b;
+    }
+  }
+  lds_barrier();
+  u32* out = sorted + task.entry_base;
+  for (u32 i = tid; i < total; i += kGroupSortThreads) out[i] = staging[i];
+}
+
 // Pass 2 with the oversized groups inside the same launch: one more row of the grid
 // (blockIdx.y == num_tasks), whose first `workers` workgroups run the chunked path.  They return at
 // once when no task has an oversized group (uniform digits: big_tasks[0] was settled by pass 1b).
