@@ -800,6 +800,13 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // ---- horner: whole columns in one launch (the range covers every window, first and last)
   if (mode.piped) ctx.reduce_done[k & 3].wait(hs);
   ctx.timer.timed(timing, 5, hs, [&] {
+    // (hundreds of columns: one-wavefront blocks, kernels.h)
+    if (num_cols >= 64 && plan.max_windows <= 64) {
+      hipLaunchKernelGGL((k_horner<C, 64>), dim3(num_cols), dim3(64), 0, hs, d_out, out_stride,
+                         projective_out ? 1 : 0, b.horner_state, b.partials, b.partial_stride, b.cols,
+                         b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1, plan.reduce_block_log2());
+      return;
+    }
     hipLaunchKernelGGL((k_horner<C>), dim3(num_cols), dim3(kCombineThreads), 0, hs, d_out,
                        out_stride, projective_out ? 1 : 0, b.horner_state, b.partials,
                        b.partial_stride, b.cols, b.tasks, b.task_total, 0u, 0xffffffffu, 1, 1,

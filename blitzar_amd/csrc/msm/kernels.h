@@ -1934,15 +1934,19 @@ __global__ void __launch_bounds__(kReduceThreads)
 // continues from state[column].  `last`: the range ends at window 0: write the canonical encoding
 // (or the raw projective point when `projective_out`); otherwise leave the chain value in
 // state[column].  The whole column in one launch = first && last with the full range.
-template <class C>
-__global__ void __launch_bounds__(kCombineThreads)
+// T: lanes per workgroup.  256 lanes fold a column's windows fastest (a lone call's last stage); a
+// launch of hundreds of columns takes 64 -- only the first wavefront walks the chain, and the other
+// three of a 256-lane block would hold a CU's LDS and registers for the length of it (1024 columns:
+// 0.67 ms at two resident blocks per CU).  W <= T windows.
+template <class C, u32 T = kCombineThreads>
+__global__ void __launch_bounds__(T)
     k_horner(u8* __restrict__ out, u32 out_stride, int projective_out,
              typename C::point* __restrict__ state, const typename C::point* __restrict__ partials,
              u32 partial_stride, const column_desc* __restrict__ columns,
              const task_desc* __restrict__ tasks, const u32* __restrict__ task_total, u32 w_lo_arg,
              u32 w_hi_arg, int first, int last, u32 reduce_block_log2) {
   using point = typename C::point;
-  __shared__ point tree[kCombineThreads];
+  __shared__ point tree[T];
   __builtin_amdgcn_s_setprio(BZ_HORNER_PRIO); // one workgroup per column, possibly beside k_accumulate
   const column_desc col = columns[blockIdx.x];
   const u32 tid = threadIdx.x;
@@ -1975,7 +1979,7 @@ __global__ void __launch_bounds__(kCombineThreads)
   }
   // lanes per window: largest power of two with W * team <= 256
   u32 team = 1;
-  while (team * 2 * W <= kCombineThreads) team *= 2;
+  while (team * 2 * W <= T) team *= 2;
   const u32 w = tid / team;
   const u32 lane = tid % team;
   const u32 nb = 1u << (col.window_bits - 1);
@@ -1994,7 +1998,7 @@ __global__ void __launch_bounds__(kCombineThreads)
       // a level with at most one addition per quad of the workgroup: the four lanes of a DPP quad
       // share each addition (the latency of ~4 field products instead of 12; on the Weierstrass
       // curves the fold is a third of a lone k_horner)
-      if (W * stride * 4 <= kCombineThreads) {
+      if (W * stride * 4 <= T) {
         const u32 a = tid >> 2;
         if (a < W * stride) {
           const u32 e = (a / stride) * team + a % stride;

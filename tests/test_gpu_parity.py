@@ -278,7 +278,9 @@ def test_many_short_columns(gpu_backend, oracle):
     in, whose tasks use a fraction of the lanes"""
     api = gpu_backend
     rng = np.random.default_rng(4096)
-    for curve_id, n, columns in ((0, 4096, 12), (2, 4096, 8), (3, 1024, 9), (1, 2048, 6)):
+    # (70 columns and more: k_horner in one-wavefront blocks too)
+    for curve_id, n, columns in ((0, 4096, 12), (2, 4096, 8), (3, 1024, 9), (1, 2048, 6), (0, 512, 70),
+                                 (2, 300, 66)):
         gens = util.generators_for(curve_id, n)
         g = util.api_generators(curve_id, gens)
         cols = [(rng.integers(0, 256, (n, 32), dtype=np.uint8), False) for _ in range(columns)]
