@@ -230,7 +230,14 @@ inline u32 ceil_div_u32(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b)
 // MI355X (bn254, 256 x 2^20, c = 15 against 16: 16.5 ms for 71 M more buckets = 0.23 ns per bucket
 // against 0.07 ns per accumulated entry) as 3.5.  (Round 1, with 8 buckets per lane whatever the
 // launch: 15 additions per bucket, which had pushed such jobs to c = 13-14.)
-inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune, double bucket_cost = 2.5) {
+// `task_cost` (launches of many columns): what a task costs whatever its size, in bucket additions --
+// its k_reduce block, its share of the sort and of k_accumulate's grid.  Fitted on 1024 columns of 256 /
+// 1024 / 4096 rows (profiles/round5_ab_many_short_columns_final.log: a task's k_reduce is 28 ns + 0.165
+// ns per bucket beside 0.048 ns per entry): without it the model took one bit too few below 4096 rows
+// (1024 rows: c = 7, 3.73 ms; c = 8, 3.50; 256 rows: c = 6, 3.02 ms; c = 7, 2.58).
+constexpr double kThroughputTaskCost = 800.0;
+inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune, double bucket_cost = 2.5,
+                              double task_cost = 0.0) {
   u32 best_c = 1;
   double best_cost = 1e300;
   const u32 cmax = tune.max_window_bits < bits + 1 ? tune.max_window_bits : bits + 1;
@@ -242,7 +249,7 @@ inline u32 choose_window_bits(u64 n, u32 bits, const msm_tuning& tune, double bu
     const u32 w = ceil_div_u32(bits + 1, c);
     const double cost =
         static_cast<double>(w) *
-        (static_cast<double>(n) + bucket_cost * static_cast<double>(1u << (c - 1)));
+        (static_cast<double>(n) + bucket_cost * static_cast<double>(1u << (c - 1)) + task_cost);
     if (cost < best_cost) {
       best_cost = cost;
       best_c = c;
@@ -304,18 +311,19 @@ inline partition_geometry choose_partition(u64 n, u32 window_bits,
 // recoded as zero digits), has more than one window and is unsigned (signed columns store -D and
 // stay at c <= 15)
 inline bool use_window_table(const host_column& hc, const window_table* tables,
-                             const msm_tuning& tune, double bucket_cost) {
+                             const msm_tuning& tune, double bucket_cost, double task_cost = 0.0) {
   if (tables == nullptr || tables->windows == 0 || hc.is_signed || hc.n == 0) return false;
   if (hc.n > tables->stride || 2 * hc.n < tables->stride) return false;
   const u32 w = ceil_div_u32(hc.bit_width + 1, tables->bits);
   if (w <= 1 || w > tables->windows) return false;
   if (tune.force_window_tables) return true;
   // same cost model as choose_window_bits: one bucket set for all windows, dearer gathers
-  const u32 c = choose_window_bits(hc.n, hc.bit_width, tune, bucket_cost);
-  const double separate = static_cast<double>(ceil_div_u32(hc.bit_width + 1, c)) *
-                          (static_cast<double>(hc.n) + bucket_cost * static_cast<double>(1u << (c - 1)));
+  const u32 c = choose_window_bits(hc.n, hc.bit_width, tune, bucket_cost, task_cost);
+  const double separate =
+      static_cast<double>(ceil_div_u32(hc.bit_width + 1, c)) *
+      (static_cast<double>(hc.n) + bucket_cost * static_cast<double>(1u << (c - 1)) + task_cost);
   const double merged = static_cast<double>(w) * static_cast<double>(hc.n) * tune.table_penalty +
-                        bucket_cost * static_cast<double>(1u << (tables->bits - 1));
+                        bucket_cost * static_cast<double>(1u << (tables->bits - 1)) + task_cost;
   return merged < separate;
 }
 
@@ -326,6 +334,7 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
   size_t nonempty = 0;
   for (const auto& c : cols) nonempty += c.n != 0 ? 1 : 0;
   const double bucket_cost = nonempty >= tune.throughput_columns ? tune.throughput_bucket_cost : 2.5;
+  const double task_cost = nonempty >= tune.throughput_columns ? kThroughputTaskCost : 0.0;
   // window width, window count and (virtual) rows per task of a column
   struct column_shape {
     bool merged;
@@ -334,8 +343,9 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
   };
   auto shape_of = [&](const host_column& hc) {
     column_shape sh{};
-    sh.merged = use_window_table(hc, tables, tune, bucket_cost);
-    sh.c = sh.merged ? tables->bits : choose_window_bits(hc.n, hc.bit_width, tune, bucket_cost);
+    sh.merged = use_window_table(hc, tables, tune, bucket_cost, task_cost);
+    sh.c = sh.merged ? tables->bits
+                     : choose_window_bits(hc.n, hc.bit_width, tune, bucket_cost, task_cost);
     sh.w = ceil_div_u32(hc.bit_width + 1, sh.c);
     // rows of a task: the column's, or every (window, row) pair up to the last window's rows
     sh.task_rows = sh.merged ? static_cast<u64>(sh.w - 1) * tables->stride + hc.n : hc.n;

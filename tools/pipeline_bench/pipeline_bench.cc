@@ -2,7 +2,7 @@
 // runs on the GPU box: no Python, no torch import -- a variant costs a second or two of box time.
 //
 //   pipeline_bench [--curve 0..3] [--log2n 20] [--columns 1] [--steps 200] [--warmup 10]
-//                  [--nbytes 32] [--null-stream] [--resident] [--skew]
+//                  [--nbytes 32] [--null-stream] [--resident] [--skew] [--window-bits c]
 //   --skew: two rows in three hold the same scalar (oversized bucket groups: the chunked sort path)
 //
 // One step = one bzamd_msm_device call of `columns` columns of 2^log2n uniform scalars (xorshift
@@ -44,6 +44,7 @@ static double now_ms() {
 int main(int argc, char** argv) {
   unsigned curve = 0, log2n = 20, columns = 1, steps = 200, warmup = 10, nbytes = 32;
   bool null_stream = false, resident = false, skew = false, no_mask = false;
+  unsigned window_bits = 0;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&] { return static_cast<unsigned>(std::atoi(argv[++i])); };
@@ -57,6 +58,7 @@ int main(int argc, char** argv) {
     else if (a == "--resident") resident = true;
     else if (a == "--skew") skew = true;
     else if (a == "--no-mask") no_mask = true; // full 256-bit scalars: the top window is as full as the others
+    else if (a == "--window-bits") window_bits = next(); // pin the window width (bzamd_set_window_bits)
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());
       return 2;
@@ -65,6 +67,7 @@ int main(int argc, char** argv) {
   const uint64_t n = uint64_t{1} << log2n;
   const sxt_config config{SXT_GPU_BACKEND, 0};
   if (sxt_init(&config) != 0) return 2;
+  if (window_bits != 0) bzamd_set_window_bits(window_bits);
   hipStream_t stream = nullptr;
   if (!null_stream) CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 

@@ -9,7 +9,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do ARGS+=("$1"); shift; done
 shift
 mkdir -p "$(dirname "$OUT")"
 EXE=tools/pipeline_bench/_build/pipeline_bench
-for rep in 1 2; do
+for rep in ${AB_REPS:-1 2}; do
 for spec in "$@"; do
   envs=${spec%@*}; lib=""
   case "$spec" in *@*) lib=${spec#*@};; esac
