@@ -852,7 +852,7 @@ def box_record(roof, state, legs, lone_call_ms, lib):
         roof["box_power_w_max"] = seq["socket_power_w"]["max"]
     if seq.get("energy_counter_mean_w") is not None:
         roof["box_power_w_energy_counter"] = seq["energy_counter_mean_w"]
-    for name in ("uclk_mhz", "socclk_mhz", "socclks_mhz_mean"):
+    for name in ("uclk_mhz", "socclk_mhz", "socclks_mhz_mean", "temperature_hotspot_c", "temperature_mem_c"):
         if seq.get(name) is not None:
             box[name + "_under_sequence"] = seq[name]
             roof["box_" + name + "_under_sequence"] = seq[name]

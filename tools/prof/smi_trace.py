@@ -57,7 +57,7 @@ def sample(amdsmi, h):
     for k in ("current_socket_power", "average_socket_power", "energy_accumulator",
               "current_gfxclk", "average_gfxclk_frequency", "ppt_residency_acc",
               "socket_thm_residency_acc", "accumulation_counter", "firmware_timestamp",
-              "temperature_hotspot"):
+              "temperature_hotspot", "temperature_mem"):
         v = _num(m.get(k))
         if v is not None:
             s[k] = v
@@ -152,6 +152,10 @@ def summarize(samples, t0, t1):
         v = [s[key] for s in win if key in s]
         if v:
             out[name] = round(sum(v) / len(v), 1)
+    for key, name in (("temperature_hotspot", "temperature_hotspot_c"), ("temperature_mem", "temperature_mem_c")):
+        v = [s[key] for s in win if key in s]
+        if v:
+            out[name] = max(v)
     soc = [c for s in win for c in s.get("socclks", [])]
     if soc:
         out["socclks_mhz_mean"] = round(sum(soc) / len(soc), 1)
