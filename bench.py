@@ -213,8 +213,8 @@ IN_RUN_ALU = {}  # filled by probe_alu(): the v_mad_u64_u32 issue rate of THIS b
 
 
 def probe_alu(lib, target_ms=50.0):
-    """v_mad_u64_u32 issue rate of this device now (bzamd_probe_mad_rate: all SIMDs at 8 waves for
-    ~50 ms, the last 4 ms launch measured); profiles/alu_calibration.json stays the fallback"""
+    """v_mad_u64_u32 issue rate of this device now (bzamd_probe_mad_rate: all SIMDs at 6 waves for
+    ~50 ms at 6 waves per SIMD, the fastest launch of its second half); profiles/alu_calibration.json stays the fallback"""
     out = (ctypes.c_double * 4)()
     if lib.bzamd_probe_mad_rate(target_ms, out) != 0 or out[0] <= 0:
         return None
@@ -251,7 +251,7 @@ def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
             peak = sum(p["wave_instructions_per_s"] for p in probes) / len(probes)
             clock_hz = sum(p["effective_clock_hz"] for p in probes) / len(probes)
             issue = sum(p["cycles_per_wave_instruction"] for p in probes) / len(probes)
-            peak_source = ("in-run: bzamd_probe_mad_rate on this device (all SIMDs at 8 waves, ~50 ms), "
+            peak_source = ("in-run: bzamd_probe_mad_rate on this device (all SIMDs at 6 waves, ~50 ms), "
                            "mean of the probes before the warm-up and after the timed region")
         else:
             cal = alu_calibration()
@@ -274,6 +274,8 @@ def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
         roof["alu_peak_wave_mads_per_s"] = peak
         roof["alu_effective_clock_hz"] = clock_hz
         roof["alu_peak_in_run"] = bool(IN_RUN_ALU.get("before"))
+        # (a kernel cannot issue more mads than the probe: if it seems to, the probe was disturbed)
+        roof["alu_probe_suspect"] = bool(roof["alu"]["frac"] > 1.0)
         roof["alu_mads_per_addition"] = mads
         if pmc and pmc.get("sq_insts_valu_per_launch"):
             roof["alu"]["valu_instructions_per_addition_pmc"] = (

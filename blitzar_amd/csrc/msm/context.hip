@@ -77,10 +77,12 @@ bool probe_slow_instruction_fetch() {
   return small > 0 && large > 1.4 * small;
 }
 
-// Issue rate of v_mad_u64_u32 on THIS device, now: every SIMD holds 8 waves, each runs 8 independent
-// chains of the instruction (the field products' one wide primitive).  A launch lasts ~4 ms; launches
-// repeat until `target_ms` of load have passed, and the LAST launch is the one measured (the part
-// clocks to its power budget under this load, not to the nominal 2.4 GHz).
+// Issue rate of v_mad_u64_u32 on THIS device, now: every SIMD holds 6 waves, each runs 8 independent
+// chains of the instruction (the field products' one wide primitive).  A launch lasts ~3 ms; launches
+// repeat until `target_ms` of load have passed, and the best of the launches of the second half is
+// reported (the part clocks to its power budget under this load, not to the nominal 2.4 GHz).
+// (6, not the 8 a SIMD can hold: a grid that fills the machine EXACTLY runs in two rounds as soon as
+// anything else holds a wave slot -- one box of round 5 reported half the rate that way.)
 constexpr int kMadProbeIters = 8192, kMadProbeChains = 8;
 __global__ void __launch_bounds__(256) k_probe_mad(u64* out, u64* ticks, u32 seed) {
   u64 a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 9, a5 = a0 * 11,
@@ -106,7 +108,8 @@ bool msm_probe_mad_rate(double target_ms, double out[4]) {
   int device = 0, cus = 0;
   BZ_HIP_CHECK(hipGetDevice(&device));
   BZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-  const u32 blocks = static_cast<u32>(cus) * 8; // 4 SIMDs per CU, 4 waves per block: 8 waves per SIMD
+  constexpr u32 kWavesPerSimd = 6;
+  const u32 blocks = static_cast<u32>(cus) * kWavesPerSimd; // 4 SIMDs per CU, 4 waves per block
   u64 *d_out = nullptr, *d_ticks = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(u64) * 256 * blocks) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&d_ticks), sizeof(u64) * blocks) != hipSuccess) {
@@ -121,8 +124,10 @@ bool msm_probe_mad_rate(double target_ms, double out[4]) {
   BZ_HIP_CHECK(hipEventCreate(&e1));
   BZ_HIP_CHECK(hipEventCreate(&first));
   BZ_HIP_CHECK(hipEventRecord(first, stream));
-  float total_ms = 0, last_ms = 0;
+  float total_ms = 0, last_ms = 0, best_ms = 0;
   u32 launches = 0;
+  u64 best_ticks = 0;
+  std::vector<u64> ticks(blocks);
   do {
     BZ_HIP_CHECK(hipEventRecord(e0, stream));
     hipLaunchKernelGGL(k_probe_mad, dim3(blocks), dim3(256), 0, stream, d_out, d_ticks, 1u + launches);
@@ -131,16 +136,20 @@ bool msm_probe_mad_rate(double target_ms, double out[4]) {
     BZ_HIP_CHECK(hipEventElapsedTime(&last_ms, e0, e1));
     BZ_HIP_CHECK(hipEventElapsedTime(&total_ms, first, e1));
     launches += 1;
+    // past the clock ramp (the second half of the load): keep the fastest launch
+    if (total_ms >= 0.5f * static_cast<float>(target_ms) && last_ms > 0 &&
+        (best_ms == 0 || last_ms < best_ms)) {
+      best_ms = last_ms;
+      BZ_HIP_CHECK(hipMemcpy(ticks.data(), d_ticks, sizeof(u64) * blocks, hipMemcpyDeviceToHost));
+      best_ticks = 0;
+      for (u64 t : ticks) best_ticks = t > best_ticks ? t : best_ticks;
+    }
   } while (total_ms < target_ms && launches < 4096);
-  std::vector<u64> ticks(blocks);
-  BZ_HIP_CHECK(hipMemcpy(ticks.data(), d_ticks, sizeof(u64) * blocks, hipMemcpyDeviceToHost));
-  u64 longest = 0;
-  for (u64 t : ticks) longest = t > longest ? t : longest;
   const double instructions_per_wave = static_cast<double>(kMadProbeIters) * kMadProbeChains;
   const double waves = static_cast<double>(blocks) * 4;
-  out[0] = instructions_per_wave * waves / (static_cast<double>(last_ms) * 1e-3);
-  out[1] = static_cast<double>(longest) / (static_cast<double>(last_ms) * 1e-3);
-  out[2] = static_cast<double>(longest) / (instructions_per_wave * 8);
+  out[0] = best_ms > 0 ? instructions_per_wave * waves / (static_cast<double>(best_ms) * 1e-3) : 0;
+  out[1] = best_ms > 0 ? static_cast<double>(best_ticks) / (static_cast<double>(best_ms) * 1e-3) : 0;
+  out[2] = static_cast<double>(best_ticks) / (instructions_per_wave * kWavesPerSimd);
   out[3] = total_ms;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -149,7 +158,7 @@ bool msm_probe_mad_rate(double target_ms, double out[4]) {
   (void)hipFree(d_out);
   (void)hipFree(d_ticks);
   g_kernel_launches += launches;
-  return last_ms > 0;
+  return best_ms > 0;
 }
 
 msm_context* msm_context_new() {

@@ -72,8 +72,9 @@ uint32_t bzamd_concurrent_calls_high_water(void);
  * k_reduce_compact), 0 if not, -1 without an initialised GPU backend */
 int bzamd_slow_instruction_fetch(void);
 /* Issue rate of v_mad_u64_u32 -- the field products' one wide primitive, the binding bound of the
- * bucket accumulation -- on the current device, measured now: every SIMD holds 8 waves of 8
- * independent chains for about `target_ms` milliseconds, the last ~4 ms launch is what is reported.
+ * bucket accumulation -- on the current device, measured now: every SIMD holds 6 waves of 8
+ * independent chains for about `target_ms` milliseconds, the fastest ~3 ms launch of the second half
+ * of that load is what is reported.
  *   out[0] wave-instructions per second over the whole device
  *   out[1] effective shader clock in Hz (s_memtime ticks of the longest wave / wall time)
  *   out[2] shader cycles per wave-instruction and SIMD
