@@ -222,8 +222,15 @@ def test_planner_invariants():
     # and the 256 buckets of a task go to 64 reduce lanes x 4
     per, totals = hooks.plan([4096] * 1024, [256] * 1024, [0] * 1024)
     assert per[0][0] == 9 and totals[6:].tolist() == [5, 2]
-    _, totals = hooks.plan([1024] * 1024, [256] * 1024, [0] * 1024)
+    per, totals = hooks.plan([1024] * 1024, [256] * 1024, [0] * 1024)
     assert totals[6] == 3
+    # ... and a task costs something whatever its size (its k_reduce block, its share of the sort): the
+    # window-width model takes one bit more than rows + buckets alone would (measured: 1024 rows c = 8,
+    # 3.50 against 3.73 ms at c = 7; 256 rows c = 7, 2.58 against 3.02 at c = 6); a lone column does not
+    assert per[0][0] == 8
+    assert hooks.plan([256] * 1024, [256] * 1024, [0] * 1024)[0][0][0] == 7
+    assert hooks.plan([1024], [256], [0])[0][0][0] == 7
+    assert hooks.plan([256], [256], [0])[0][0][0] == 6
     # ... by the task a typical ENTRY lives in: one 2^22-row column among 200 columns of 256 rows keeps
     # the long column's geometry (its 17 tasks hold 99.9 % of the entries)
     _, totals = hooks.plan([1 << 22] + [256] * 200, [256] * 201, [0] * 201)
