@@ -192,7 +192,7 @@ struct msm_plan {
 #define BZ_THROUGHPUT_BUCKET_COST 3.5
 #endif
 struct msm_tuning {
-  u32 max_window_bits = 16; // digits are stored as int16
+  u32 max_window_bits = 16; // separate windows store their digits as int16 (merged tasks of wide tables: int32)
   // batching of many-column jobs: tasks per launch (grid.y) and device workspace per batch
   size_t max_tasks_per_batch = 65000; // (tasks + 1 is a launch-grid dimension: at most 65535)
   size_t max_workspace_bytes = size_t{64} << 30;
@@ -206,7 +206,7 @@ struct msm_tuning {
   u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
   u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
   // throughput mode (engine.h, msm_context): calls with this many columns or more ignore
-  // bzamd_pipeline_next (BLITZAR_AMD_DEFER_COLUMNS).  Measured on MI355X, curve25519, k columns x 2^20
+  // bzamd_pipeline_next.  Measured on MI355X, curve25519, k columns x 2^20
   // rows, ms per call lone / in sequence (tools/multi_column_bench.py): 2: 2.41 / 2.03, 4: 4.19 / 3.73,
   // 8: 7.60 / 7.13, 16: 14.46 / 13.93, 32: 27.73 / 27.22; with 256 columns (bn254) the fork and the
   // second set of tail buffers cost more than the overlap buys (352.5 against 348.0).
