@@ -101,3 +101,43 @@ def test_caller_stream_with_a_cu_mask(oracle, tmp_path):
     cols = np.load(cols_file)
     want = oracle.commit(0, [(cols[0], False), (cols[1], False)], util.generators_for(0, n))
     assert np.array_equal(got, want)
+
+
+def test_bench_box_record_from_a_trace_summary():
+    """bench.py `box_record`: `roofline.box` and the flat scalars the driver's record keeps, from what
+    device_state + the SMI trace hand it; and nothing breaks when the trace has nothing"""
+    import importlib.util
+    import types
+    torch_stub = None
+    try:
+        import torch  # noqa: F401  (bench.py imports it at module level)
+    except Exception:  # pragma: no cover
+        torch_stub = types.ModuleType("torch")
+        sys.modules["torch"] = torch_stub
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Lib:
+        @staticmethod
+        def bzamd_slow_instruction_fetch():
+            return 1
+
+    seq = {"samples": 120, "hz": 50.0, "socket_power_w": {"min": 1370, "mean": 1380.5, "max": 1390},
+           "sclk_mhz": {"min": 2300, "mean": 2335.0, "max": 2360}, "energy_counter_mean_w": 1381.0,
+           "power_limited_share": 0.7, "uclk_mhz": 2000.0, "temperature_mem_c": 55}
+    state = {"trace": {"static": {"asic_serial": "0xABC", "power_cap_w": 1400.0},
+                       "under_sequence_load": seq,
+                       "under_lone_call_load": {"socket_power_w": {"min": 1000, "mean": 1040.0, "max": 1100}}},
+             "sequence_leg": {"ms_per_step_last_2500": 0.985}}
+    roof = {}
+    bench.box_record(roof, state, {"sustained_ms": 0.99}, 1.42, Lib)
+    assert roof["box_asic_serial"] == "0xABC" and roof["box_fetch_kind"] == "slow-fetch"
+    assert roof["box_sclk_mhz_under_sequence"] == 2335.0 and roof["box_power_w_mean"] == 1380.5
+    assert roof["box_power_w_energy_counter"] == 1381.0 and roof["box_lone_call_ms"] == 1.42
+    assert roof["box_sustained_ms_per_step"] == 0.985 and roof["box_temperature_mem_c_under_sequence"] == 55
+    assert roof["box"]["lone_leg"]["socket_power_w"]["mean"] == 1040.0
+    assert all(not isinstance(v, (dict, list)) for k, v in roof.items() if k != "box")
+    empty = {}
+    bench.box_record(empty, {"trace": {}}, {}, 1.2, Lib)   # amdsmi unavailable: still a record
+    assert empty["box_fetch_kind"] == "slow-fetch" and empty["box"]["socket_power_w"] is None
