@@ -13,17 +13,20 @@ configs[1]).  Inputs are resident in HBM before the timed region.  With N ranks 
 independent columns (columns shard) followed by one RCCL all-gather of the N 32-byte
 commitments -- weak scaling.
 
-Prints ONE JSON line (rank 0): metric = scalar-point ops / s over the whole job.  Extra members:
+The LAST stdout line (rank 0) is ONE compact strict-JSON record (< 4 KB, `compact_record`):
+metric = scalar-point ops / s over the whole job, plus
   roofline      dominant kernel k_accumulate: algorithmic bytes per launch / its HIP-event duration
-                against 8 TB/s, plus the integer-ALU side (the binding bound) normalised to the
-                v_mad_u64_u32 issue rate measured on THIS box in THIS run, and `box`: which box ran
-                (serial, fetch kind, shader clock and socket power under the sustained leg from a
-                50 Hz amdsmi trace) -- every such figure also as a flat scalar of `roofline`
+                against 8 TB/s; `traffic` / `valu_busy` from the committed PMC passes; `alu_frac` =
+                the integer-ALU side (the binding bound) against the v_mad_u64_u32 issue rate
+                measured on THIS box in THIS run; `box_*`: which kind of box ran, its sustained step
+                and lone call -- flat scalars only
   cpu_baseline  N = 1 only: the reference's own CPU backend (oracle/_ref) on THE SAME scalars; the
                 timed GPU commitment must equal its output or the bench aborts (`verified`)
-  configs       N = 1: BASELINE configs 1, 3, 4, 5 at their stated shapes on one GPU, each with
-                ms_per_call, its roofline, a bounded cpu_baseline sample and a full-size parity
-                check of every output; N > 1: config 4's 256 columns sharded over the ranks
+The full record (every leg, nested) goes to gpurun_out/bench_detail.json (--detail-file).  With
+--detail the untimed legs that only feed that file run too: BASELINE configs 1, 3, 4, 5 at their
+stated shapes on one GPU (each with its roofline, a bounded cpu_baseline sample and a full-size
+parity check), the 50 Hz power / clock trace, the host-buffer (PCIe-inclusive) figures.  N > 1:
+config 4's 256 columns sharded over the ranks and config 2 row-split run by default.
 """
 import argparse
 import ctypes
@@ -67,6 +70,14 @@ def parse_args():
     ap.add_argument("--log2n", type=int, default=None, help="override rows (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the reference-CPU leg (and with it the output verification)")
+    ap.add_argument("--detail", action="store_true",
+                    help="also run the untimed legs that only feed the detail file: configs 1/3/4/5 at "
+                         "full shape, the 50 Hz device-state trace, the host-buffer (PCIe) figures, the "
+                         "one-process multi-device check (minutes; the default run is the headline, its "
+                         "roofline and the reference-CPU baseline)")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the full record goes (default gpurun_out/bench_detail.json beside "
+                         "bench.py); the LAST stdout line is the compact record")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/4/5 legs")
     ap.add_argument("--skip-headline-check", action="store_true",
                     help="profiling runs: keep the oracle for the configs legs but skip the 16 s "
@@ -834,7 +845,8 @@ def box_record(roof, state, legs, lone_call_ms, lib):
            "socket_power_w_energy_counter": seq.get("energy_counter_mean_w"),
            "power_limited_share": seq.get("power_limited_share"),
            "trace_hz": seq.get("hz"), "trace_samples": seq.get("samples"),
-           "sustained_ms_per_step": state.get("sequence_leg", {}).get("ms_per_step_last_2500"),
+           "sustained_ms_per_step": (state.get("sequence_leg", {}).get("ms_per_step_last_2500")
+                                     or legs.get("sustained_ms")),
            "sustained_ms_per_step_before_warmup": legs.get("sustained_ms"),
            "lone_call_ms": lone_call_ms,
            "lone_leg": {"sclk_mhz": lone.get("sclk_mhz"), "socket_power_w": lone.get("socket_power_w"),
@@ -842,7 +854,8 @@ def box_record(roof, state, legs, lone_call_ms, lib):
            "idle": tr.get("idle"),
            "power_cap_w": static.get("power_cap_w")}
     roof["box"] = box
-    roof["box_asic_serial"] = str(box["asic_serial"])
+    if box["asic_serial"] is not None:
+        roof["box_asic_serial"] = str(box["asic_serial"])
     roof["box_fetch_kind"] = fetch
     roof["box_sustained_ms_per_step"] = box["sustained_ms_per_step"]
     roof["box_lone_call_ms"] = lone_call_ms
@@ -864,6 +877,107 @@ def box_record(roof, state, legs, lone_call_ms, lib):
 
 
 #--------------------------------------------------------------------------------------------------
+#--------------------------------------------------------------------------------------------------
+# the record: ONE compact strict-JSON line, last on stdout; everything else in a sidecar file
+#--------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 4096
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                 "algorithmic_bytes_per_launch", "kernel_ms", "valu_busy", "alu_frac")
+BOX_KEYS = ("box_fetch_kind", "box_asic_serial", "box_sustained_ms_per_step", "box_lone_call_ms",
+            "box_sclk_mhz_under_sequence", "box_power_w_mean")
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _finite(v):
+    """strict JSON has no NaN / Infinity: they become null"""
+    if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
+        return None
+    if isinstance(v, dict):
+        return {k: _finite(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_finite(x) for x in v]
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return _finite(float(v))
+    return v
+
+
+def _round(v, digits=6):
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def compact_record(result):
+    """the driver's line: the contract's members, `roofline` and `cpu_baseline` as flat objects of
+    scalars, `verified`, and a handful of scalars beside them -- never a nested leg"""
+    out = {k: result[k] for k in TOP_KEYS if k in result}
+    out["dtype"] = "u32"  # the arithmetic type; the limb form is in DESIGN.md section 5
+    out["data"] = "synthetic"
+    roof = result.get("roofline")
+    if roof:
+        out["roofline"] = {k: _round(roof.get(k)) for k in ROOFLINE_KEYS}
+        out["roofline"].update({k: _round(roof[k]) for k in BOX_KEYS if roof.get(k) is not None})
+    cpu = result.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {"value": _round(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"],
+                               "kind": cpu["kind"], "sample": cpu["sample"][:200]}
+    out["verified"] = bool(result.get("verified"))
+    for k in ("commitments_per_s", "single_call_ms", "sustained_ms_per_step", "effective_warmup_calls",
+              "resident_generators_ms_per_step"):
+        if result.get(k) is not None:
+            out[k] = _round(result[k])
+    if "stage_ms" in result:
+        out["stage_ms"] = result["stage_ms"]
+    if "configs" in result:
+        out["configs_ms_per_call"] = {c["config"].split(":")[0]: _round(c["ms_per_call"], 4)
+                                      for c in result["configs"] if "ms_per_call" in c}
+    for name in ("strong_scaling", "strong_scaling_config2"):
+        leg = result.get(name)
+        if isinstance(leg, dict):
+            out[name] = {k: _round(v) for k, v in leg.items()
+                         if isinstance(v, (int, float, bool)) or (isinstance(v, str) and len(v) < 80)}
+            if "verified" in leg:
+                out[name]["verified"] = bool(leg["verified"])
+    if "distributed" in result:
+        d = result["distributed"]
+        out["distributed"] = {k: d[k] for k in ("backend", "rccl_world_size", "distinct_devices",
+                                                "distinct_commitments_gathered") if k in d}
+    if result.get("detail_file"):
+        out["detail_file"] = result["detail_file"]
+    out = {k: _round(v) for k, v in _finite(out).items()}
+    line = json.dumps(out, allow_nan=False, separators=(", ", ": "))
+    # (whatever a later edit adds: the line stays under the limit; the optional members go first)
+    for k in ("stage_ms", "strong_scaling_config2", "strong_scaling", "configs_ms_per_call",
+              "distributed", "detail_file"):
+        if len(line) < COMPACT_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out, allow_nan=False, separators=(", ", ": "))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(result, args):
+    """full record -> the detail file (and stderr); compact record -> the LAST line on stdout"""
+    path = args.detail_file
+    if path is None:
+        path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(_finite(result), fh, indent=1, allow_nan=False)
+            fh.write("\n")
+        result["detail_file"] = os.path.relpath(path, ROOT)
+    except OSError as exc:
+        print(f"[bench] could not write {path}: {exc}", file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_record(result), flush=True)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -900,7 +1014,10 @@ def main():
 
     lib = api.load()
     assert api.init(api.SXT_GPU_BACKEND, 0) == 0
-    trace = SmiTrace() if (rank == 0 and world == 1 and not args.no_aux) else None
+    # the untimed single-GPU legs that only feed the detail file run under --detail
+    aux_legs = args.detail and not args.no_aux
+    config_legs = args.detail and not args.no_configs
+    trace = SmiTrace() if (rank == 0 and world == 1 and aux_legs) else None
     # a stream of the bench's own (callers on the NULL stream work too, the engine then uses plain
     # non-blocking tail streams: include/blitzar_amd.h, bzamd_pipeline_next)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
@@ -1204,7 +1321,11 @@ def main():
                     box_record(result["roofline"], state, legs, single_call_ms, lib)
             except Exception as exc:  # never at the price of the line
                 result["device_state"] = {"error": repr(exc)[:300]}
-        if world == 1 and not args.no_configs and args.log2n is None:
+        elif "roofline" in result:
+            # no trace (the default run): the box's kind, its sustained step and its lone call
+            box_record(result["roofline"], {}, legs, single_call_ms, lib)
+            del result["roofline"]["box"]
+        if world == 1 and config_legs and args.log2n is None:
             result["configs"] = run_configs(lib, oracle, args, dev, stream)
         if sharded is not None:
             result["configs"] = [sharded]
@@ -1234,26 +1355,11 @@ def main():
         # has released its GPU and the process group: a failure there cannot touch the line above
         # (more than one visible device only: a lone device would exchange with itself, and mapping
         # the 570 MB librccl for that costs up to a minute on a fresh box)
-        if not args.no_configs and not args.dry_run_one_gpu and torch.cuda.device_count() > 1:
+        if config_legs and not args.dry_run_one_gpu and torch.cuda.device_count() > 1:
             result["in_process_multi_device"] = in_process_multi_device()
-        if world == 1 and not args.no_configs and args.log2n is None and not args.no_aux:
+        if world == 1 and config_legs and aux_legs and args.log2n is None:
             result["host_api"] = host_api(oracle, headline_gens)
-        # last member of the line (logs that keep only its tail still get the essentials): the step,
-        # the dominant kernel, which box ran and at what clocks / power, the other configs
-        roof = result.get("roofline", {})
-        summary = {"ms_per_step": result["ms_per_step"], "ops_per_s": result["value"],
-                   "k_accumulate_ms": roof.get("kernel_ms"), "hbm_frac": roof.get("frac"),
-                   "alu_frac_in_run": roof.get("alu_frac"), "verified": bool(result.get("verified")),
-                   "box": {k[4:]: roof[k] for k in roof if k.startswith("box_")}}
-        if "configs" in result:
-            summary["configs_ms_per_call"] = {c["config"].split(":")[0]: round(c["ms_per_call"], 3)
-                                              for c in result["configs"] if "ms_per_call" in c}
-        warm = result.get("host_api", {}).get("warm", {}).get("cases")
-        if warm:
-            summary["host_api_ms"] = {f"{c['columns']}col_{c['generators'].split()[0]}": c["ms_mean"]
-                                      for c in warm}
-        result["summary"] = summary
-        print(json.dumps(result), flush=True)
+        emit(result, args)
 
 
 if __name__ == "__main__":

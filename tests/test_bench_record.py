@@ -1,0 +1,86 @@
+"""bench.py's record: the LAST stdout line is one compact strict-JSON object under 4 KB with the
+contract's members, `roofline` and `cpu_baseline` as flat objects; everything else goes to a sidecar
+file.  (Round 5's single 24 KB line could not be recovered by the driver: BENCH_r05.parsed == null.)
+The canned input is that very record, profiles/round5_bench_final.json."""
+import importlib.util
+import io
+import json
+import os
+import types
+from contextlib import redirect_stdout
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_record_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _strict(line):
+    def refuse(name):
+        raise ValueError(f"{name} is not JSON")
+    return json.loads(line, parse_constant=refuse)
+
+
+def _canned():
+    with open(os.path.join(ROOT, "profiles", "round5_bench_final.json")) as fh:
+        return json.load(fh)
+
+
+def test_compact_record_is_small_strict_and_complete(bench):
+    full = _canned()
+    assert len(json.dumps(full)) > 20000  # the record that broke the driver's parse
+    line = bench.compact_record(full)
+    assert len(line) < 4096 and "\n" not in line
+    d = _strict(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verified"):
+        assert k in d, k
+    assert d["config"]["workload"] == full["config"]["workload"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(full["value"], rel=1e-5) and d["verified"] is True
+    roof = d["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+              "algorithmic_bytes_per_launch", "kernel_ms", "valu_busy", "alu_frac", "box_fetch_kind"):
+        assert k in roof, k
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+    # achieved = algorithmic bytes per launch / the kernel's duration
+    assert roof["achieved"] == pytest.approx(
+        roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9, rel=1e-4)
+    assert all(not isinstance(v, (dict, list)) for v in roof.values())
+    cpu = d["cpu_baseline"]
+    assert set(cpu) == {"value", "unit", "cores", "kind", "sample"} and cpu["kind"] == "reference"
+    assert all(not isinstance(v, (dict, list)) for v in cpu.values())
+
+
+def test_compact_record_survives_nan_and_oversized_members(bench):
+    full = _canned()
+    full["roofline"]["traffic"] = float("nan")
+    full["stage_ms"] = {f"stage_{i}": 0.001 * i for i in range(400)}     # an over-eager later edit
+    full["strong_scaling"] = {"ms_per_call": float("inf"), "verified": "bit-exact ...", "columns_per_gpu": 32}
+    line = bench.compact_record(full)
+    assert len(line) < 4096
+    d = _strict(line)
+    assert d["roofline"]["traffic"] is None and "stage_ms" not in d
+    assert d["strong_scaling"] == {"ms_per_call": None, "verified": True, "columns_per_gpu": 32}
+
+
+def test_emit_prints_the_compact_record_last_and_writes_the_sidecar(bench, tmp_path):
+    full = _canned()
+    args = types.SimpleNamespace(detail_file=str(tmp_path / "sub" / "detail.json"))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(full, args)
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096          # nothing before or after it on stdout
+    d = _strict(lines[-1])
+    with open(tmp_path / "sub" / "detail.json") as fh:
+        detail = _strict(fh.read())
+    assert detail["configs"] and detail["host_api"] and detail["value"] == full["value"]
+    assert "detail_file" in d
