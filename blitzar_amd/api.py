@@ -145,6 +145,8 @@ def load():
     lib.bzamd_num_devices.restype = ctypes.c_int
     lib.bzamd_set_window_bits.argtypes = [u32]
     lib.bzamd_set_window_bits.restype = None
+    lib.bzamd_set_call_tables.argtypes = [ctypes.c_int]
+    lib.bzamd_set_call_tables.restype = ctypes.c_uint64
     lib.bzamd_set_max_rows_per_pass.argtypes = [u64]
     lib.bzamd_set_max_rows_per_pass.restype = None
     lib.bzamd_device_id.argtypes = [ctypes.c_int]

@@ -262,14 +262,22 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   if (gens.source == generator_source::host_api) {
     u8* d_api = ds.io.take<u8>(vt.api_generator_size * longest + 32);
     void* prepared = ds.io.take<u8>(vt.addend_size * (longest + 1));
+    d_addends = prepared;
     if (longest > 0) {
       BZ_HIP_CHECK(hipMemcpyAsync(d_api, gens.host_generators, vt.api_generator_size * longest,
                                   hipMemcpyHostToDevice, ds.copy_stream));
       signal(ds.copy_stream, ds.stream);
-      vt.prepare_addends(prepared, d_api, longest, ds.stream);
-      g_kernel_launches += 1;
+      // many columns over these generators: their window table, built once for all column chunks
+      // of the call (msm/plan.h, choose_call_table), instead of the plain per-call addends
+      const void* table = vt.call_table(*ds.ctx, cols, d_api, &tables, ds.stream);
+      if (table != nullptr) {
+        d_addends = table;
+        resident = true;
+      } else {
+        vt.prepare_addends(prepared, d_api, longest, ds.stream);
+        g_kernel_launches += 1;
+      }
     }
-    d_addends = prepared;
   } else if (gens.offset <= st.host_generators.size() &&
              longest <= st.host_generators.size() - gens.offset &&
              ds.builtin.d_addends != nullptr) {
@@ -1503,6 +1511,16 @@ void bzamd_set_window_bits(uint32_t window_bits) {
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "tuning applies to the GPU backend");
   msm_context_set_window_bits(st.context_for_current_device(), window_bits);
   for (auto& d : st.devices) msm_context_set_window_bits(d->ctx, window_bits);
+}
+
+uint64_t bzamd_set_call_tables(int mode) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "tuning applies to the GPU backend");
+  uint64_t built = msm_context_set_call_tables(st.context_for_current_device(), mode);
+  for (auto& d : st.devices) {
+    if (d->ctx != st.context_for_current_device()) built += msm_context_set_call_tables(d->ctx, mode);
+  }
+  return built;
 }
 
 void bzamd_set_segments(uint32_t log2_entries_per_accumulate_lane,

@@ -184,6 +184,14 @@ msm_context* msm_context_new() {
     if (const char* v = std::getenv(name)) out = !(v[0] == '0' && v[1] == 0);
   };
   flag("BLITZAR_AMD_OVERLAP_TAILS", ctx->overlap_tails);
+  flag("BLITZAR_AMD_CALL_TABLES", ctx->call_tables);
+  flag("BLITZAR_AMD_CALL_TABLE_OVERLAP", ctx->table_overlap);
+  if (const char* v = std::getenv("BLITZAR_AMD_CALL_TABLE_BITS")) {
+    const unsigned long b = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(b == 0 || (b >= kCallTableMinBits && b <= kCallTableMaxBits),
+                      "BLITZAR_AMD_CALL_TABLE_BITS must be 0 or in [6, 16]");
+    ctx->force_call_table_bits = static_cast<u32>(b);
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_COMPACT_REDUCE")) {
     const unsigned long m = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(m <= 2, "BLITZAR_AMD_COMPACT_REDUCE must be 0 (never), 1 (always) or 2 (probe)");
@@ -221,6 +229,17 @@ void msm_context_set_window_bits(msm_context* ctx, u32 window_bits) {
                     "window width must be 2..16 (0 = automatic)");
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->tuning.force_window_bits = window_bits;
+}
+u64 msm_context_set_call_tables(msm_context* ctx, int mode) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (mode >= 0) {
+    BZ_RELEASE_ASSERT(mode <= 1 || (mode >= static_cast<int>(kCallTableMinBits) &&
+                                    mode <= static_cast<int>(kCallTableMaxBits)),
+                      "call tables: 0 (model), 1 (never) or a width in [6, 16]");
+    ctx->call_tables = mode != 1;
+    ctx->force_call_table_bits = mode > 1 ? static_cast<u32>(mode) : 0;
+  }
+  return ctx->call_tables_built;
 }
 void msm_context_defer_next_tail(msm_context* ctx) {
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -47,6 +47,7 @@ struct ed25519_msm {
   // one spills: the kernel is issue-bound, not latency-bound)
   static constexpr int accumulate_waves_per_simd = 3;
   static constexpr bool has_batched_prepare = false;
+  static constexpr double call_table_entry_cost = 1.0;
 
   BZ_HD static point identity() { return ed29::identity(); }
   BZ_HD static point add(const point& a, const point& b) { return ed29::add(a, b); }
@@ -198,6 +199,9 @@ struct ed25519_niels_msm : ed25519_msm {
     acc = ed29::add_niels(acc, q, negate);
   }
   static constexpr bool has_signed_gather = false; // 36-byte limb pieces: no aligned exchange
+  // an accumulated entry against Z = 1 addends relative to the per-call (Y+X, Y-X, Z, 2dT) form
+  // (7 of 8 field products, nothing to unpack: plan.h, choose_call_table)
+  static constexpr double call_table_entry_cost = 0.88;
   using operand = ed29_niels; // stored as limbs: nothing to unpack
   BZ_HD static operand stage(const addend& q) {
     operand o = q;
@@ -243,6 +247,7 @@ struct ed25519_niels_msm : ed25519_msm {
 // generators enter and where a result leaves (conversions + the existing ABI-form encoders).
 template <class G29, unsigned CurveId> struct sw_msm_base {
   static constexpr unsigned curve_id = CurveId;
+  static constexpr double call_table_entry_cost = 1.0; // (per-call and resident addends are the same)
   using G64 = typename G29::G64;       // ABI-form curve (curve/weierstrass.h)
   using F64 = typename G64::F;
   static constexpr int N64 = F64::N;

@@ -79,6 +79,23 @@ __global__ void __launch_bounds__(256)
   points[i] = R::dbl_n(points[i], doublings);
 }
 
+// Per-call window tables (plan.h, choose_call_table): points[w * stride + i] = 2^(bits w) g_i for
+// every slice in ONE launch -- a lane walks its generator's whole chain of doublings (the chain is
+// what the build costs: one-wavefront blocks spread the few lanes of a short generator set over as
+// many compute units as there are) -- rows between the set's end and the slice's are identities.
+template <class R>
+__global__ void __launch_bounds__(64)
+    k_chain_points(typename R::point* __restrict__ points, const void* __restrict__ api_generators,
+                   u64 n, u64 stride, u32 windows, int bits) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= stride) return;
+  typename R::point p = i < n ? R::point_from_api_generator(api_generators, i) : R::identity();
+  for (u32 w = 0; w < windows; ++w) {
+    points[static_cast<u64>(w) * stride + i] = p;
+    if (w + 1 < windows && i < n) p = R::dbl_n(p, bits);
+  }
+}
+
 // addends[i] = the affine (Z = 1) addend of points[i]; a workgroup's points share one inversion
 // (tree_products / tree_inverses, msm/kernels.h)
 template <class R>
@@ -130,8 +147,16 @@ template <class C, class R = C, class H = C> struct curve_tu {
   static void msm_resident(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                            const std::vector<host_column>& cols, const void* d_addends,
                            hipStream_t stream, const window_table* tables) {
-    msm_enqueue<R>(ctx, d_out, out_stride, projective_out, cols,
-                   static_cast<const typename R::addend*>(d_addends), nullptr, stream, tables);
+    if (cols.empty()) return;
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    configure_sort_kernels(ctx);
+    ctx.order_after_previous(stream);
+    // (a forced per-call table -- tests, A/B runs -- merges whatever the cost model says)
+    const bool force = ctx.force_call_table_bits != 0 && tables != nullptr &&
+                       d_addends == ctx.call_table_rows;
+    msm_enqueue_locked<R>(ctx, d_out, out_stride, projective_out, cols,
+                          static_cast<const typename R::addend*>(d_addends), nullptr, stream, tables,
+                          force);
   }
   // slices 0 .. windows-1 of a resident set: d_table[w * stride + i] = addend of 2^(bits w) g_i
   // (blocking: scratch for the chain of points is allocated and freed here)
@@ -173,11 +198,87 @@ template <class C, class R = C, class H = C> struct curve_tu {
                        static_cast<const typename R::api_projective*>(d_projective), n);
     BZ_HIP_CHECK(hipGetLastError());
   }
+  // the 2^(bits w) multiples of a call's caller generators in the resident addend form, into the
+  // context's table block; asynchronous (side stream beside the call's front, or the caller's)
+  static const typename R::addend* build_call_table(msm_context& ctx, const void* d_api_generators,
+                                                    u64 n, const window_table& t,
+                                                    hipStream_t stream) {
+    using point = typename R::point;
+    using addend = typename R::addend;
+    const u64 rows = t.stride * t.windows;
+    ctx.call_table.reset(device_arena::padded(sizeof(addend) * (rows + 1)) +
+                             device_arena::padded(sizeof(point) * (rows + 1)),
+                         stream);
+    addend* table = ctx.call_table.take<addend>(rows + 1);
+    point* points = ctx.call_table.take<point>(rows + 1);
+    hipStream_t bs = stream;
+    if (ctx.table_overlap) {
+      ctx.make_side_stream();
+      ctx.table_fork.record(stream);
+      ctx.table_fork.wait(ctx.side);
+      bs = ctx.side;
+    }
+    hipLaunchKernelGGL((k_chain_points<R>), dim3(ceil_div_u32(t.stride, 64)), dim3(64), 0, bs, points,
+                       d_api_generators, n, t.stride, t.windows, static_cast<int>(t.bits));
+    hipLaunchKernelGGL((k_points_to_addends<R>),
+                       dim3(ceil_div_u32(rows, 256ull * R::batch_points_per_lane)), dim3(256), 0, bs,
+                       table, points, rows);
+    BZ_HIP_CHECK(hipGetLastError());
+    g_kernel_launches += 2;
+    ctx.call_tables_built += 1;
+    ctx.call_table_rows = table;
+    if (ctx.table_overlap) {
+      ctx.table_ready.record(bs);
+      ctx.table_pending = true;
+    }
+    return table;
+  }
+  // the model's choice for `cols` and, if it wants a table, the enqueued build (ctx.mu held)
+  static const typename R::addend* call_table_locked(msm_context& ctx,
+                                                     const std::vector<host_column>& cols,
+                                                     const void* d_api_generators,
+                                                     window_table& shape, hipStream_t stream) {
+    shape = window_table{};
+    shape.windows = 0;
+    if (!ctx.call_tables || d_api_generators == nullptr) return nullptr;
+    const call_table_choice ch =
+        choose_call_table(cols, ctx.tuning, sizeof(typename R::addend), R::call_table_entry_cost,
+                          ctx.force_call_table_bits);
+    if (ch.shape.windows == 0) return nullptr;
+    u64 n = 0;
+    for (const auto& c : cols) n = c.n > n ? c.n : n;
+    shape = ch.shape;
+    return build_call_table(ctx, d_api_generators, n, shape, stream);
+  }
+  static const void* call_table(msm_context& ctx, const std::vector<host_column>& cols,
+                                const void* d_api_generators, window_table* shape,
+                                hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    ctx.order_after_previous(stream);
+    const void* table = call_table_locked(ctx, cols, d_api_generators, *shape, stream);
+    if (table != nullptr) ctx.mark_enqueued(stream);
+    return table;
+  }
   static void msm(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                   const std::vector<host_column>& cols, const void* d_addends,
                   const void* d_api_generators, hipStream_t stream) {
-    msm_enqueue<C>(ctx, d_out, out_stride, projective_out, cols,
-                   static_cast<const typename C::addend*>(d_addends), d_api_generators, stream);
+    if (cols.empty()) return;
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    configure_sort_kernels(ctx);
+    ctx.order_after_previous(stream);
+    // many columns over the same caller generators (the reference's bucket_method2 regime): the
+    // window table of the generators is built in the call and every column becomes one task
+    if (d_addends == nullptr) {
+      window_table shape;
+      const typename R::addend* table = call_table_locked(ctx, cols, d_api_generators, shape, stream);
+      if (table != nullptr) {
+        msm_enqueue_locked<R>(ctx, d_out, out_stride, projective_out, cols, table, nullptr, stream,
+                              &shape, ctx.force_call_table_bits != 0);
+        return;
+      }
+    }
+    msm_enqueue_locked<C>(ctx, d_out, out_stride, projective_out, cols,
+                          static_cast<const typename C::addend*>(d_addends), d_api_generators, stream);
   }
   static void prepare_addends(void* d_addends, const void* d_api_generators, u64 n,
                               hipStream_t stream) {
@@ -274,6 +375,7 @@ template <class C, class R = C, class H = C> struct curve_tu {
                                  &curve_tu::prepare_resident,
                                  &curve_tu::prepare_resident_projective,
                                  &curve_tu::build_window_table,
+                                 &curve_tu::call_table,
                                  sizeof(typename compact_ops<H>::compact),
                                  &write_partition_table<H>,
                                  &write_partition_table_device<H>,

@@ -61,6 +61,12 @@ struct curve_vtable {
   // w < windows, from C-ABI generators or projective elements on the device (blocking)
   void (*build_window_table)(void* d_table, const void* d_source, bool source_projective, u64 n,
                              u64 stride, u32 windows, u32 bits, hipStream_t stream);
+  // Per-call window table (plan.h, choose_call_table): when the cost model wants one for `cols`
+  // (only their shapes are read) over the caller generators `d_api_generators`, enqueue its build
+  // and return its slice 0 -- resident-form addends for msm_resident with `*shape` -- else nullptr.
+  // The table lives in the context until the next one is built there.
+  const void* (*call_table)(msm_context& ctx, const std::vector<host_column>& cols,
+                            const void* d_api_generators, window_table* shape, hipStream_t stream);
   // partition-table file interop of fixed-base handles (fixed/partition_table.h)
   size_t compact_size;
   bool (*write_partition_table)(std::FILE* f, unsigned window_width, const void* projective, u64 n);
@@ -95,6 +101,9 @@ void msm_context_set_tuning(msm_context* ctx, u32 max_window_bits, size_t max_ta
                             size_t max_workspace_bytes);
 // tests: every column takes this window width where it can (0 = the cost model chooses)
 void msm_context_set_window_bits(msm_context* ctx, u32 window_bits);
+// per-call window tables (engine.h, msm_context): mode 0 = the cost model decides (default), 1 = never,
+// 6..16 = a table of that width for every call with caller generators; returns the tables built so far
+u64 msm_context_set_call_tables(msm_context* ctx, int mode);
 // throughput mode (bzamd_msm_device_pipelined): the next MSM enqueued on this context leaves its last
 // stages running on the context's own streams; `join_tail` makes `stream` wait for everything pending
 void msm_context_defer_next_tail(msm_context* ctx);

@@ -154,6 +154,27 @@ struct msm_context {
   // fork / join pair costs ~25 us of stream bubbles).
   hipStream_t tail = nullptr, tail2 = nullptr; // k_reduce / k_horner of a pipelined batch
   stage_mark acc_done[4], reduce_done[4], horner_done[4];
+  // Per-call window tables (plan.h, choose_call_table; built by curve_tu.h, build_call_table): the
+  // 2^(c w) multiples of a call's caller generators, rebuilt by every call that wants them into this
+  // grow-only block.  Only k_accumulate reads the table, so the build -- a chain of W c dependent
+  // doublings per generator on a handful of wavefronts, then one normalisation launch -- runs on a
+  // side stream beside the recoding and the sort of the same call (`table_overlap`;
+  // BLITZAR_AMD_CALL_TABLE_OVERLAP=0 keeps it on the caller's stream) and the accumulation waits for
+  // `table_ready`.  BLITZAR_AMD_CALL_TABLES=0 switches the tables off, BLITZAR_AMD_CALL_TABLE_BITS=c
+  // (6..16) forces a table of that width for every call with caller generators (tests, A/B runs).
+  device_arena call_table;
+  hipStream_t side = nullptr;
+  stage_mark table_fork, table_ready;
+  bool table_pending = false;
+  bool call_tables = true;
+  bool table_overlap = true;
+  u32 force_call_table_bits = 0;
+  u64 call_tables_built = 0; // (tests: bzamd_set_call_tables returns it)
+  const void* call_table_rows = nullptr; // slice 0 of the table built last
+  void make_side_stream() {
+    if (side != nullptr) return;
+    BZ_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  }
   u64 seq = 0;            // pipelined batches enqueued so far on this context
   u64 joined = 0;         // the caller's stream `joined_on` has waited for every batch below this
   hipStream_t joined_on = nullptr;
@@ -256,7 +277,9 @@ struct msm_context {
       reduce_done[i].destroy();
       horner_done[i].destroy();
     }
-    for (hipStream_t s : {tail2, tail}) {
+    table_fork.destroy();
+    table_ready.destroy();
+    for (hipStream_t s : {side, tail2, tail}) {
       if (s != nullptr) (void)hipStreamDestroy(s);
     }
   }
@@ -359,6 +382,15 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
 // Columns are processed in batches bounded by the launch grid (tasks per batch) and by
 // `msm_tuning::max_workspace_bytes`; batches reuse the same arena back to back on the stream.
 // `tables`: `d_addends` is slice 0 of a window table (plan.h) whose further slices follow it.
+// (`msm_enqueue_locked`: the caller holds ctx.mu, has configured the kernels and ordered `stream`
+// behind the previous call -- curve_tu.h builds a per-call window table in between;
+// `force_tables`: merge every column the table allows, whatever the cost model says)
+template <class C>
+void msm_enqueue_locked(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                        const std::vector<host_column>& cols, const typename C::addend* d_addends,
+                        const void* d_api_generators, hipStream_t stream,
+                        const window_table* tables = nullptr, bool force_tables = false);
+
 template <class C>
 void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
                  const std::vector<host_column>& cols, const typename C::addend* d_addends,
@@ -368,6 +400,15 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   std::lock_guard<std::mutex> lock(ctx.mu);
   configure_sort_kernels(ctx);
   ctx.order_after_previous(stream);
+  msm_enqueue_locked<C>(ctx, d_out, out_stride, projective_out, cols, d_addends, d_api_generators,
+                        stream, tables);
+}
+
+template <class C>
+void msm_enqueue_locked(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_out,
+                        const std::vector<host_column>& cols, const typename C::addend* d_addends,
+                        const void* d_api_generators, hipStream_t stream,
+                        const window_table* tables, bool force_tables) {
   // throughput mode is for latency-bound tails: with hundreds of columns k_reduce and k_horner
   // fill the machine themselves (plan.h, defer_max_columns), so such a call ignores the request
   // and completes on the caller's stream
@@ -378,6 +419,9 @@ void msm_enqueue(msm_context& ctx, u8* d_out, u32 out_stride, bool projective_ou
   ctx.defer_tail = false;
   msm_tuning tune = ctx.tuning;
   tune.in_sequence = mode.piped;
+  if (force_tables) tune.force_window_tables = true;
+  tune.accumulate_wave_slots =
+      static_cast<u32>(C::accumulate_waves_per_simd) * 4 * ctx.stream_cus(stream);
   bool any_signed = false;
   for (const auto& c : cols) any_signed = any_signed || c.is_signed;
   // Signed columns use |x| with all digits negated: cap c at 15 so that -D fits int16 either way.
@@ -752,6 +796,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
 
   // ---- accumulate: rewrites the bucket sums / head partials the reduce two batches ago read
   wait_for(earlier(ctx.reduce_done, 2), as);
+  if (ctx.table_pending) {
+    // the call's window table, built on the side stream beside this front
+    ctx.table_ready.wait(as);
+    ctx.table_pending = false;
+  }
   ctx.timer.timed(timing, 3, as, [&] {
     hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
                        as, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,

@@ -203,6 +203,10 @@ struct msm_tuning {
   double throughput_bucket_cost = BZ_THROUGHPUT_BUCKET_COST;
   u32 force_window_bits = 0;         // tests (bzamd_set_window_bits): this width wherever a column allows it
   bool in_sequence = false; // set per call by msm_enqueue: the call runs in throughput mode
+  // wavefronts of k_accumulate the device holds at once (waves per SIMD of the curve's loop x SIMDs;
+  // set per call by msm_enqueue, 0 = unknown): make_msm_plan shortens the segments of a launch whose
+  // wavefronts would fill the device a few times only and leave its last round mostly idle
+  u32 accumulate_wave_slots = 0;
   u32 force_reduce_segment_log2 = 0; // development override (BLITZAR_AMD_REDUCE_SEGMENT_LOG2), 0 = choose
   u32 force_segment_log2 = 0;        // development override (BLITZAR_AMD_SEGMENT_LOG2), 0 = choose
   // throughput mode (engine.h, msm_context): calls with this many columns or more ignore
@@ -327,6 +331,119 @@ inline bool use_window_table(const host_column& hc, const window_table* tables,
   return merged < separate;
 }
 
+// Per-call window tables (the reference's bucket_method2 regime: many columns over the SAME caller
+// generators, sxt/multiexp/bucket_method2/multiexponentiation.h:48-121).  A launch of hundreds of short
+// columns pays W separate windows per column -- 29 tasks of 256 buckets each at 4096 rows -- because
+// every window owns a bucket set; with the 2^(c w) multiples of the call's generators built once IN
+// the call (W c doublings per generator, shared by every column) a column is ONE task with one
+// bucket set, and c can grow: 1024 x 4096 x 256-bit: 29 x (4096 + 3.5 x 256 + 800) = 168 K units per
+// column on separate 9-bit windows against 22 x 4096 + 3.5 x 2048 + 800 = 98 K merged at c = 12.
+// The build is priced in the same unit (one bucket addition at the machine's throughput): a doubling
+// ~0.8, the normalisation of a slice row ~0.5, plus what the chain of W c dependent doublings costs
+// in idle machine when nothing hides it (`kCallTableLatencyUnits`, ~0.1 ms).
+struct call_table_choice {
+  window_table shape; // shape.windows == 0: no table for this call
+  double separate_cost = 0, merged_cost = 0, build_cost = 0;
+};
+constexpr u32 kCallTableMinBits = 6;
+constexpr u32 kCallTableMaxBits = 16;
+constexpr size_t kCallTableMinColumns = 8;
+constexpr double kCallTableLatencyUnits = 2.5e6;
+constexpr double kCallTableMaxBytes = 4.0 * (u64{1} << 30);
+// `entry_cost`: an accumulated entry against the table's addend form relative to the per-call form
+// (curve25519: Z = 1 addends, 7 field products instead of 8)
+inline call_table_choice choose_call_table(const std::vector<host_column>& cols,
+                                           const msm_tuning& tune, size_t addend_size,
+                                           double entry_cost = 1.0, u32 force_bits = 0) {
+  call_table_choice out;
+  u64 max_n = 0;
+  size_t nonempty = 0;
+  for (const auto& c : cols) {
+    if (c.n == 0) continue;
+    ++nonempty;
+    if (c.n > max_n) max_n = c.n;
+  }
+  if (nonempty < (force_bits != 0 ? 1 : kCallTableMinColumns) || max_n == 0) return out;
+  if (nonempty < tune.throughput_columns && force_bits == 0) return out;
+  const u64 stride = (max_n + 7) & ~u64{7};
+  // distinct column shapes (a call's columns mostly share one)
+  struct shape_count {
+    u64 n;
+    u32 bits;
+    bool is_signed;
+    size_t count;
+  };
+  std::vector<shape_count> shapes;
+  for (const auto& c : cols) {
+    if (c.n == 0) continue;
+    bool found = false;
+    for (auto& s : shapes) {
+      if (s.n == c.n && s.bits == c.bit_width && s.is_signed == c.is_signed) {
+        ++s.count;
+        found = true;
+        break;
+      }
+    }
+    if (!found) {
+      if (shapes.size() >= 64) return out; // a ragged call: not the regime
+      shapes.push_back({c.n, c.bit_width, c.is_signed, 1});
+    }
+  }
+  const double bucket_cost = tune.throughput_bucket_cost, task_cost = kThroughputTaskCost;
+  auto separate_of = [&](const shape_count& s) {
+    msm_tuning t = tune;
+    if (s.is_signed && t.max_window_bits > 15) t.max_window_bits = 15;
+    const u32 c = choose_window_bits(s.n, s.bits, t, bucket_cost, task_cost);
+    return static_cast<double>(ceil_div_u32(s.bits + 1, c)) *
+           (static_cast<double>(s.n) + bucket_cost * static_cast<double>(1u << (c - 1)) + task_cost);
+  };
+  double separate_total = 0;
+  for (const auto& s : shapes) separate_total += separate_of(s) * static_cast<double>(s.count);
+  out.separate_cost = separate_total;
+  double best = separate_total;
+  const u32 lo = force_bits != 0 ? force_bits : kCallTableMinBits;
+  const u32 hi = force_bits != 0 ? force_bits : kCallTableMaxBits;
+  u32 widest = 0;
+  for (const auto& s : shapes) widest = s.bits > widest ? s.bits : widest;
+  for (u32 c = lo; c <= hi; ++c) {
+    u32 windows = 0;
+    double total = 0;
+    // gathers from a table beyond the Infinity Cache are dearer (msm_tuning::table_penalty; the
+    // same figures msm_enqueue prices a resident table with)
+    const double table_bytes = static_cast<double>(addend_size) * static_cast<double>(stride) *
+                               ceil_div_u32(widest + 1, c);
+    const double penalty = table_bytes > 200.0 * (1 << 20) ? 1.15 : 1.03;
+    for (const auto& s : shapes) {
+      const u32 w = ceil_div_u32(s.bits + 1, c);
+      const bool can = !s.is_signed && w > 1 && 2 * s.n >= stride;
+      const double merged = static_cast<double>(w) * static_cast<double>(s.n) * entry_cost * penalty +
+                            bucket_cost * static_cast<double>(1u << (c - 1)) + task_cost;
+      const double sep = separate_of(s) * entry_cost; // (plain columns gather slice 0: the same form)
+      if (can && (merged < sep || force_bits != 0)) {
+        total += merged * static_cast<double>(s.count);
+        if (w > windows) windows = w;
+      } else {
+        total += sep * static_cast<double>(s.count);
+      }
+    }
+    if (windows < 2) continue;
+    if (static_cast<double>(addend_size) * static_cast<double>(stride) * windows > kCallTableMaxBytes) {
+      continue;
+    }
+    const double build = static_cast<double>(max_n) * (0.8 * c * (windows - 1) + 0.5 * windows) +
+                         kCallTableLatencyUnits;
+    if (total + build < best || (force_bits != 0 && out.shape.windows == 0)) {
+      best = total + build;
+      out.shape.stride = stride;
+      out.shape.windows = windows;
+      out.shape.bits = c;
+      out.merged_cost = total;
+      out.build_cost = build;
+    }
+  }
+  return out;
+}
+
 inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tuning& tune = {},
                               const window_table* tables = nullptr) {
   msm_plan plan;
@@ -356,6 +473,10 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
   // rows: one long column among a thousand short ones keeps its own geometry)
   u64 launch_entries = 0;
   double rows_squared = 0;
+  struct task_run {
+    u64 rows, tasks;
+  };
+  std::vector<task_run> runs; // (rows, count) of the launch's tasks, equal neighbours folded
   for (const auto& hc : cols) {
     if (hc.n == 0) continue;
     const column_shape sh = shape_of(hc);
@@ -363,12 +484,38 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     launch_entries += sh.task_rows * tasks;
     rows_squared += static_cast<double>(sh.task_rows) * static_cast<double>(sh.task_rows) *
                     static_cast<double>(tasks);
+    if (!runs.empty() && runs.back().rows == sh.task_rows) {
+      runs.back().tasks += tasks;
+    } else {
+      runs.push_back({sh.task_rows, tasks});
+    }
   }
   const u64 typical_task_rows =
       launch_entries != 0 ? static_cast<u64>(rows_squared / static_cast<double>(launch_entries)) : 0;
   plan.segment_log2 = tune.force_segment_log2 != 0
                           ? tune.force_segment_log2
                           : choose_segment_log2(launch_entries, typical_task_rows);
+  // Rounds.  A wavefront of k_accumulate works through 64 segments of equal length, so the launch's
+  // wavefronts all take about the same time and the device runs them in rounds of
+  // `accumulate_wave_slots`: 1024 merged tasks of 20 x 4096 rows at 128 entries per lane are 10240
+  // wavefronts = 3.33 rounds of 3072 and take the time of FOUR (measured: k_accumulate 3.43 ms at 84 M
+  // entries and 3.39 ms at 100 M, which are 3.97 rounds).  While the last round is less than 90 % full
+  // and there are fewer than 12 rounds, halve the segments (down to 32 entries: twice the head
+  // partials for k_reduce, which is the cheaper side).
+  if (tune.force_segment_log2 == 0 && tune.accumulate_wave_slots != 0) {
+    auto rounds_at = [&](u32 s) {
+      u64 waves = 0;
+      for (const auto& r : runs) waves += r.tasks * ((r.rows + (u64{64} << s) - 1) / (u64{64} << s));
+      return static_cast<double>(waves) / static_cast<double>(tune.accumulate_wave_slots);
+    };
+    while (plan.segment_log2 > kSegmentLog2) {
+      const double rounds = rounds_at(plan.segment_log2);
+      const double whole = static_cast<double>(static_cast<u64>(rounds));
+      const double up = whole < rounds ? whole + 1 : whole;
+      if (rounds >= 12 || rounds >= 0.9 * up) break;
+      --plan.segment_log2;
+    }
+  }
   const u64 seg_entries = u64{1} << plan.segment_log2;
   for (size_t ci = 0; ci < cols.size(); ++ci) {
     const host_column& hc = cols[ci];
@@ -391,8 +538,18 @@ inline msm_plan make_msm_plan(const std::vector<host_column>& cols, const msm_tu
     const u32 c = sh.c, w = sh.w;
     const u32 buckets = 1u << (c - 1);
     const u64 task_rows = sh.task_rows;
-    const partition_geometry geo =
-        choose_partition(task_rows, c, tune.partition_group_entries);
+    // A merged task's top slice is not uniform: scalars below 2^252 in 256-bit fields leave a few bits
+    // (or only the carry) to the top window, so ALL of that slice's rows land in the lowest bucket
+    // group, on top of the group's share of the other slices.  With short slices (per-call tables of a
+    // few thousand generators) size the groups so that share + slice still fits the LDS stage of pass 2
+    // -- otherwise every task has one oversized group, streamed by a single workgroup (1024 x 4096
+    // rows, c = 13: sort 1.06 ms against 0.55 at c = 11, whose top slice holds carries only).
+    u32 group_entries = tune.partition_group_entries;
+    if (merged && tables->stride < kLocalSortCapacity - 1024) {
+      const u32 room = kLocalSortCapacity - static_cast<u32>(tables->stride);
+      if (room < group_entries) group_entries = room;
+    }
+    const partition_geometry geo = choose_partition(task_rows, c, group_entries);
     const u32 slices = geo.num_slices;
     cd.window_bits = c;
     cd.num_windows = w;

@@ -94,6 +94,14 @@ void bzamd_set_tuning(uint32_t max_window_bits, uint64_t max_tasks_per_batch,
  * the width the cost model would choose from its length (0 restores the model).  For tests: the
  * c = 16 code paths at sizes a CPU reference finishes in seconds. */
 void bzamd_set_window_bits(uint32_t window_bits);
+/* Per-call window tables: a call of many columns over the same caller generators (the reference's
+ * bucket_method2 regime, sxt/multiexp/bucket_method2/multiexponentiation.h:48-121) builds the
+ * 2^(c w) multiples of its generators once, inside the call, and runs every column as ONE task with
+ * one bucket set.  mode 0 = the cost model decides (default), 1 = never, 6..16 = a table of that
+ * window width for every call with caller generators (tests, A/B runs), negative = change nothing.
+ * Returns the number of tables built so far on the backend's contexts.  Results never depend on it.
+ * Env: BLITZAR_AMD_CALL_TABLES=0, BLITZAR_AMD_CALL_TABLE_BITS=c, BLITZAR_AMD_CALL_TABLE_OVERLAP=0. */
+uint64_t bzamd_set_call_tables(int mode);
 /* Work per lane of the two bucket kernels, as log2 (0, the default, lets every launch choose from
  * its size): sorted entries per accumulation lane (2^3..2^10; 32 for a single column so that its
  * lanes fill the machine, up to 128 when hundreds of columns do -- every segment leaves one partial

@@ -183,6 +183,18 @@ def plan_tables(ns, bit_widths, signed, stride, windows, force=False, table_pena
     return per, totals
 
 
+def choose_call_table(ns, bit_widths, signed, addend_size=64, entry_cost=1.0, force_bits=0):
+    """plan.h choose_call_table -> (stride, windows, bits), (separate, merged, build) costs"""
+    out = np.zeros(3, np.uint64)
+    costs = np.zeros(3, np.float64)
+    fn = lib().bz_choose_call_table
+    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double, ctypes.c_uint32]
+    fn.restype = None
+    fn(_p(out), _p(costs), _p(_c(ns)), _p(_c(bit_widths, np.uint32)), _p(_c(signed, np.int32)),
+       len(ns), addend_size, entry_cost, force_bits)
+    return tuple(int(v) for v in out), tuple(float(v) for v in costs)
+
+
 def packed_ranges(offsets, strides, bit_offsets, bit_widths):
     """column ranges k_recode_packed would use: list of (first_column, num_columns, base, span)"""
     k = len(offsets)

@@ -249,6 +249,23 @@ void bz_plan_tables(u32* per_column, u64* totals, const u64* n, const u32* bit_w
   }
 }
 
+// choose_call_table (msm/plan.h): out = {stride, windows, bits}, costs = {separate, merged, build}
+void bz_choose_call_table(u64* out, double* costs, const u64* n, const u32* bit_width,
+                          const int* is_signed, u32 num_columns, u64 addend_size, double entry_cost,
+                          u32 force_bits) {
+  std::vector<host_column> cols(num_columns);
+  for (u32 i = 0; i < num_columns; ++i) {
+    cols[i] = host_column{nullptr, n[i], (bit_width[i] + 7) / 8, 0, bit_width[i], is_signed[i] != 0};
+  }
+  const call_table_choice ch = choose_call_table(cols, msm_tuning{}, addend_size, entry_cost, force_bits);
+  out[0] = ch.shape.stride;
+  out[1] = ch.shape.windows;
+  out[2] = ch.shape.bits;
+  costs[0] = ch.separate_cost;
+  costs[1] = ch.merged_cost;
+  costs[2] = ch.build_cost;
+}
+
 // column ranges of k_recode_packed (msm/plan.h): columns = bit fields at byte offsets `offset[i]`
 // of rows `stride[i]` bytes apart; out = {first_column, num_columns, base offset, span} per range;
 // returns the number of ranges (0: not a packed batch)
