@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "blitzar_amd/csrc/base/log.h"
 #include "blitzar_amd/csrc/api/rccl_loader.h"
 #include "blitzar_amd/csrc/api/state.h"
 #include "blitzar_amd/csrc/fixed/dump.h"
@@ -802,6 +803,21 @@ void compute_commitments(const curve_vtable& vt, void* commitments, u32 num_sequ
   if (num_sequences == 0) return; // reference: returns before touching anything
   BZ_RELEASE_ASSERT(commitments != nullptr, "commitments is null");
   api_state& st = state();
+  // (one line as the call starts, one as it completes: bucket_method2/multiexponentiation.h:55,71)
+  struct call_log {
+    u32 outputs;
+    u64 longest = 0;
+    call_log(u32 num, const sxt_sequence_descriptor* d) : outputs{num} {
+      if (!log::enabled(log::info) || d == nullptr) return;
+      for (u32 i = 0; i < num; ++i) longest = d[i].n > longest ? d[i].n : longest;
+      BZ_LOG_INFO("compute a multiexponentiation with %u outputs of length %llu", outputs,
+                  static_cast<unsigned long long>(longest));
+    }
+    ~call_log() {
+      BZ_LOG_INFO("finished multiexponentiation with %u outputs of length %llu", outputs,
+                  static_cast<unsigned long long>(longest));
+    }
+  } logged{num_sequences, descriptors};
   if (st.backend != SXT_GPU_BACKEND) { // the host backend keeps no per-call state: no lock
     compute_commitments_locked(st, vt, commitments, num_sequences, descriptors, generators, source,
                                offset_generators, projective_out, nullptr);
@@ -827,6 +843,7 @@ int backend_from_environment(int backend) {
   if (val == nullptr) return backend;
   std::string s{val};
   for (auto& c : s) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+  BZ_LOG_INFO("override default backend with environmental variable BLITZAR_BACKEND=%s", s.c_str());
   if (s == "cpu") return SXT_CPU_BACKEND;
   if (s == "gpu") return SXT_GPU_BACKEND;
   std::fprintf(stderr, "blitzar_amd: invalid BLITZAR_BACKEND value %s\n", val);
@@ -866,6 +883,7 @@ int sxt_init(const struct sxt_config* config) {
   if (backend != SXT_GPU_BACKEND && backend != SXT_CPU_BACKEND) return 1;
   auto st = std::make_unique<api_state>();
   st->backend = backend;
+  BZ_LOG_INFO(backend == SXT_GPU_BACKEND ? "initializing GPU backend" : "initializing CPU backend");
   if (backend == SXT_GPU_BACKEND) {
     // no silent fallback: a GPU backend without a GPU is a hard error, as in the reference
     // (cbindings/backend.cc:61-63 "no supported GPUs found")
@@ -1005,7 +1023,10 @@ namespace {
 unsigned partition_window_width() {
   // reference: sxt/multiexp/pippenger2/window_width.cc:30-44
   const char* val = std::getenv("BLITZAR_PARTITION_WINDOW_WIDTH");
-  if (val == nullptr) return 16;
+  if (val == nullptr) {
+    BZ_LOG_INFO("using a default partition window width of %u", 16u);
+    return 16;
+  }
   const long w = std::strtol(val, nullptr, 10);
   BZ_RELEASE_ASSERT(w > 0 && w <= 32, "invalid BLITZAR_PARTITION_WINDOW_WIDTH");
   return static_cast<unsigned>(w);
@@ -1042,6 +1063,19 @@ void fixed_multiexponentiation(void* res, const multiexp_handle& h, const unsign
   if (num_outputs == 0) return;
   BZ_RELEASE_ASSERT(res != nullptr, "res is null");
   api_state& st = state();
+  if (log::enabled(log::info) && record) {
+    // (pippenger2/multiexponentiation.h:254,261)
+    unsigned long long products = 0;
+    for (unsigned k = 0; k < num_outputs; ++k) products += bit_table != nullptr ? bit_table[k] : uniform_bits;
+    BZ_LOG_INFO("computing %llu bitwise multiexponentiation products of length %u", products, n);
+  }
+  struct done_log {
+    unsigned outputs;
+    bool on;
+    ~done_log() {
+      if (on) BZ_LOG_INFO("completed %u reductions", outputs);
+    }
+  } done{num_outputs, record};
   // An output wider than 256 bits (the reference takes any unsigned width,
   // cbindings/blitzar_api.h:712, pippenger2/multiexponentiation.h:207-288: a bit plane per bit): the
   // engine's columns are scalars of at most 256 bits, so such an output is computed as

@@ -48,6 +48,7 @@
 #include "sxt/multiexp/pippenger2/in_memory_partition_table_accessor.h"
 #include "sxt/multiexp/pippenger2/in_memory_partition_table_accessor_utility.h"
 #include "sxt/multiexp/pippenger2/multiexponentiation.h"
+#include "sxt/multiexp/pippenger2/multiexponentiation_serialization.h"
 #include "sxt/multiexp/pippenger2/partition_table_accessor_base.h"
 #include "sxt/multiexp/pippenger2/variable_length_multiexponentiation.h"
 
@@ -154,6 +155,72 @@ void ref_fixed_vlen_multiexponentiation(void* res, const void* handle,
         res_span, static_cast<const mtxpp2::partition_table_accessor<U>&>(*h.accessor), bits,
         lengths, scalars_span);
   });
+}
+
+// BLITZAR_DUMP_DIR recordings: the reference's own writer and reader
+// (multiexponentiation_serialization.h:70-151), called as gpu_backend.cc:286-301,317-332 calls the
+// writer; `result.bin` is written by the caller of these (gpu_backend.cc:298-300: the raw result
+// elements).  The readers hand back a handle over the accessor the reference rebuilt from
+// generators.bin + window_width.bin, and the descriptor's vectors.
+void ref_write_packed_multiexponentiation(const char* dir, const void* handle,
+                                          const unsigned* output_bit_table, unsigned num_outputs,
+                                          unsigned n, const uint8_t* scalars) {
+  const auto& h = *static_cast<const fixed_handle*>(handle);
+  with_curve(h.curve_id, [&]<class U, class T>(std::type_identity<U>, std::type_identity<T>) {
+    basct::cspan<unsigned> bits{output_bit_table, num_outputs};
+    auto output_num_bytes = basn::divide_up<size_t>(
+        std::accumulate(output_bit_table, output_bit_table + num_outputs, size_t{0}), 8);
+    basct::cspan<uint8_t> scalars_span{scalars, output_num_bytes * n};
+    mtxpp2::write_multiexponentiation<T>(
+        dir, static_cast<const mtxpp2::partition_table_accessor<U>&>(*h.accessor), bits,
+        scalars_span);
+  });
+}
+
+void ref_write_vlen_multiexponentiation(const char* dir, const void* handle,
+                                        const unsigned* output_bit_table,
+                                        const unsigned* output_lengths, unsigned num_outputs,
+                                        const uint8_t* scalars) {
+  const auto& h = *static_cast<const fixed_handle*>(handle);
+  with_curve(h.curve_id, [&]<class U, class T>(std::type_identity<U>, std::type_identity<T>) {
+    basct::cspan<unsigned> bits{output_bit_table, num_outputs};
+    basct::cspan<unsigned> lengths{output_lengths, num_outputs};
+    auto scalars_span = cbnbck::make_scalars_span(scalars, bits, lengths);
+    mtxpp2::write_multiexponentiation<T>(
+        dir, static_cast<const mtxpp2::partition_table_accessor<U>&>(*h.accessor), bits, lengths,
+        scalars_span);
+  });
+}
+
+// sizes[0..2] = entries of output_bit_table / output_lengths (0 for a packed recording) / bytes of
+// scalars; a second call with the arrays copies them out
+void* ref_read_multiexponentiation(const char* dir, unsigned curve_id, int vlen, uint64_t* sizes,
+                                   unsigned* output_bit_table, unsigned* output_lengths,
+                                   uint8_t* scalars) {
+  auto h = new fixed_handle{curve_id, nullptr};
+  with_curve(curve_id, [&]<class U, class T>(std::type_identity<U>, std::type_identity<T>) {
+    auto copy_out = [&](const std::vector<unsigned>& bits, const std::vector<unsigned>& lengths,
+                        const std::vector<uint8_t>& sc) {
+      sizes[0] = bits.size();
+      sizes[1] = lengths.size();
+      sizes[2] = sc.size();
+      if (output_bit_table != nullptr) std::copy(bits.begin(), bits.end(), output_bit_table);
+      if (output_lengths != nullptr) std::copy(lengths.begin(), lengths.end(), output_lengths);
+      if (scalars != nullptr) std::copy(sc.begin(), sc.end(), scalars);
+    };
+    if (vlen != 0) {
+      mtxpp2::variable_length_multiexponentiation_descriptor<T, U> descr;
+      mtxpp2::read_multiexponentiation(descr, dir);
+      copy_out(descr.output_bit_table, descr.output_lengths, descr.scalars);
+      h->accessor = std::move(descr.accessor);
+    } else {
+      mtxpp2::packed_multiexponentiation_descriptor<T, U> descr;
+      mtxpp2::read_multiexponentiation(descr, dir);
+      copy_out(descr.output_bit_table, {}, descr.scalars);
+      h->accessor = std::move(descr.accessor);
+    }
+  });
+  return h;
 }
 
 // The reference's GPU control flow of the same three calls (gpu_backend.cc:259-333:

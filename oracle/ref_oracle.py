@@ -280,6 +280,43 @@ class FixedHandle:
         return res
 
 
+    # BLITZAR_DUMP_DIR recordings through the reference's own writer / reader
+    # (multiexponentiation_serialization.h:70-151; ref_fixed_base.cc)
+    def write_dump(self, directory, bit_table, scalars, lengths=None, n=None):
+        """what gpu_backend.cc:286-301 / :317-332 records BEFORE the computation (result.bin -- the raw
+        result elements, :298-300 -- is the caller's to add)"""
+        bt = np.ascontiguousarray(bit_table, dtype=np.uint32)
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1)
+        if lengths is None:
+            lib().ref_write_packed_multiexponentiation(directory.encode(), self._h, _p(bt),
+                                                       ctypes.c_uint(bt.size), ctypes.c_uint(n), _p(s))
+        else:
+            ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+            lib().ref_write_vlen_multiexponentiation(directory.encode(), self._h, _p(bt), _p(ln),
+                                                     ctypes.c_uint(bt.size), _p(s))
+
+    @classmethod
+    def read_dump(cls, curve_id, directory, vlen=False):
+        """-> (handle over the accessor the reference rebuilt from generators.bin + window_width.bin,
+        output_bit_table, output_lengths or None, scalars)"""
+        L = lib()
+        L.ref_read_multiexponentiation.restype = ctypes.c_void_p
+        sizes = np.zeros(3, np.uint64)
+        probe = ctypes.c_void_p(L.ref_read_multiexponentiation(
+            directory.encode(), ctypes.c_uint(curve_id), ctypes.c_int(int(vlen)), _p(sizes), None,
+            None, None))
+        L.ref_fixed_handle_free(probe)
+        bt = np.zeros(int(sizes[0]), np.uint32)
+        ln = np.zeros(int(sizes[1]), np.uint32)
+        sc = np.zeros(int(sizes[2]), np.uint8)
+        self = cls.__new__(cls)
+        self.curve_id = curve_id
+        self._h = ctypes.c_void_p(L.ref_read_multiexponentiation(
+            directory.encode(), ctypes.c_uint(curve_id), ctypes.c_int(int(vlen)), _p(sizes), _p(bt),
+            _p(ln) if vlen else None, _p(sc)))
+        return self, bt, (ln if vlen else None), sc
+
+
 #--------------------------------------------------------------------------------------------------
 # inner-product argument (oracle/ref/ref_inner_product.cc: the reference's own prover / verifier)
 #--------------------------------------------------------------------------------------------------

@@ -182,6 +182,88 @@ def dump_record_and_replay(api, backend_id, oracle, cid, tmp_path, monkeypatch):
     assert np.array_equal(canon(oracle, cid, res), GOLDEN[f"curve{cid}_fixed_canonical"])
 
 
+def dump_interop_with_the_reference(api, backend_id, oracle, cid, tmp_path, monkeypatch):
+    """f2 against the reference's OWN writer and reader (multiexponentiation_serialization.h:70-151,
+    compiled in place into the oracle library), both directions, packed and vlen:
+      1. a recording the reference wrote (its write_multiexponentiation over its own accessor, result.bin
+         = the raw elements its multiexponentiate returned, as gpu_backend.cc:298-300 writes them)
+         replays through this library to the same canonical bytes;
+      2. a recording THIS library wrote is read by the reference's read_multiexponentiation -- which
+         rebuilds its accessor from our generators.bin + window_width.bin -- to the descriptor we were
+         called with, and the reference's multiexponentiate over it gives our result.bin (canonical);
+      3. the two recordings of one call are byte-identical file by file, meta.txt (the typeid names
+         the reference writes) included."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import replay_dump
+    proj = GOLDEN[f"curve{cid}_fixed_projective_generators"]
+    n = proj.shape[0]
+    width = 4
+    bt = np.asarray(GOLDEN["fixed_bit_table"], np.uint32)
+    sc = np.asarray(GOLDEN[f"curve{cid}_fixed_scalars"], np.uint8).reshape(-1)
+    vbt, vln = np.array([4, 12, 1], np.uint32), np.array([0, 5, n], np.uint32)
+    vsc = np.random.default_rng(2).integers(0, 256, (n, 3), dtype=np.uint8).reshape(-1)
+    ref = oracle.FixedHandle(cid, proj, width)
+    # 1. written by the reference
+    theirs = {}
+    for kind, args in (("packed", dict(bit_table=bt, scalars=sc, n=n)),
+                       ("vlen", dict(bit_table=vbt, scalars=vsc, lengths=vln))):
+        d = tmp_path / f"ref-{kind}"
+        d.mkdir()
+        ref.write_dump(str(d), **args)
+        res = (ref.packed_multiexponentiation(bt, n, sc) if kind == "packed"
+               else ref.vlen_multiexponentiation(vbt, vln, vsc, gpu_flow=True))
+        res.tofile(d / "result.bin")
+        theirs[kind] = d
+        assert replay_dump.replay(str(d), backend_id) == (cid, len(args["bit_table"]), True)
+    # 2. written by this library
+    ours_root = tmp_path / "ours"
+    ours_root.mkdir()
+    monkeypatch.setenv("BLITZAR_DUMP_DIR", str(ours_root))
+    monkeypatch.setenv("BLITZAR_PARTITION_WINDOW_WIDTH", str(width))
+    h = api.MultiexpHandle(cid, proj)
+    h.packed_multiexponentiation(bt, n, sc)
+    h.vlen_multiexponentiation(vbt, vln, vsc)
+    h.close()
+    monkeypatch.delenv("BLITZAR_DUMP_DIR")
+    ours = {d.rsplit("-", 2)[0]: ours_root / d for d in sorted(os.listdir(ours_root))}
+    for kind in ("packed", "vlen"):
+        mine = ours[kind]
+        back, r_bt, r_ln, r_sc = oracle.FixedHandle.read_dump(cid, str(mine), vlen=kind == "vlen")
+        if kind == "packed":
+            assert np.array_equal(r_bt, bt) and r_ln is None and np.array_equal(r_sc, sc)
+            again = back.packed_multiexponentiation(r_bt, n, r_sc)
+        else:
+            assert np.array_equal(r_bt, vbt) and np.array_equal(r_ln, vln) and np.array_equal(r_sc, vsc)
+            again = back.vlen_multiexponentiation(r_bt, r_ln, r_sc, gpu_flow=True)
+        back.close()
+        recorded = np.fromfile(mine / "result.bin", np.uint8).reshape(len(r_bt), -1)
+        assert np.array_equal(canon(oracle, cid, again), canon(oracle, cid, recorded))
+        # 3. file by file
+        for name in sorted(os.listdir(theirs[kind])):
+            if name == "result.bin":
+                continue  # projective, not canonical: compared above
+            assert (mine / name).read_bytes() == (theirs[kind] / name).read_bytes(), (kind, name)
+        assert sorted(os.listdir(mine)) == sorted(os.listdir(theirs[kind]))
+    ref.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_dump_dir_interop_with_the_reference(cpu_backend, oracle, cid, tmp_path, monkeypatch):
+    dump_interop_with_the_reference(cpu_backend, cpu_backend.SXT_CPU_BACKEND, oracle, cid, tmp_path,
+                                    monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_dump_dir_interop_with_the_reference_gpu(gpu_backend, oracle, cid, tmp_path, monkeypatch):
+    before = gpu_backend.load().bzamd_kernel_launch_count()
+    dump_interop_with_the_reference(gpu_backend, gpu_backend.SXT_GPU_BACKEND, oracle, cid, tmp_path,
+                                    monkeypatch)
+    assert gpu_backend.load().bzamd_kernel_launch_count() > before
+
+
 @pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_dump_dir_record_and_replay(cpu_backend, oracle, cid, tmp_path, monkeypatch):
     dump_record_and_replay(cpu_backend, cpu_backend.SXT_CPU_BACKEND, oracle, cid, tmp_path,
