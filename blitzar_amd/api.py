@@ -145,6 +145,8 @@ def load():
     lib.bzamd_num_devices.restype = ctypes.c_int
     lib.bzamd_set_window_bits.argtypes = [u32]
     lib.bzamd_set_window_bits.restype = None
+    lib.bzamd_generator_cache_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 2
+    lib.bzamd_generator_cache_stats.restype = None
     lib.bzamd_set_call_tables.argtypes = [ctypes.c_int]
     lib.bzamd_set_call_tables.restype = ctypes.c_uint64
     lib.bzamd_set_max_rows_per_pass.argtypes = [u64]

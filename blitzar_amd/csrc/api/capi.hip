@@ -151,7 +151,77 @@ struct generator_ref {
   generator_source source;
   const void* host_generators; // host_api: C-ABI layout, first generator of the range
   u64 offset;                  // builtin: index of the first generator
+  // host_api generators this device already holds as a resident set (BLITZAR_AMD_GENERATOR_CACHE,
+  // api/state.h): nothing of them is uploaded or converted
+  const resident_table* cached = nullptr;
 };
+
+// hash of a 1-in-256 sample of the rows (every 256th and the last), whole rows, 8 bytes at a time
+u64 sample_hash_of(const void* generators, u64 n, size_t row_bytes) {
+  const u8* base = static_cast<const u8*>(generators);
+  u64 h = 0x9e3779b97f4a7c15ull ^ n;
+  auto mix_row = [&](u64 i) {
+    const u8* row = base + i * row_bytes;
+    for (size_t k = 0; k + 8 <= row_bytes; k += 8) {
+      u64 w;
+      std::memcpy(&w, row + k, 8);
+      h = (h ^ w) * 0xff51afd7ed558ccdull;
+      h ^= h >> 29;
+    }
+  };
+  for (u64 i = 0; i < n; i += 256) mix_row(i);
+  if (n != 0) mix_row(n - 1);
+  return h;
+}
+
+constexpr u64 kGeneratorCacheMinRows = u64{1} << 14;
+
+// The resident set for the caller's host generators on this device, or nullptr (first sightings,
+// short sets, knob off).  Called with the device's lease held.
+const resident_table* cached_caller_generators(api_state& st, device_state& ds,
+                                               const curve_vtable& vt, const void* generators,
+                                               u64 n) {
+  if (!st.generator_cache || generators == nullptr || n < kGeneratorCacheMinRows) return nullptr;
+  const u64 hash = sample_hash_of(generators, n, vt.api_generator_size);
+  generator_cache_entry* hit = nullptr;
+  generator_cache_entry* victim = &ds.caller_cache[0];
+  for (auto& e : ds.caller_cache) {
+    if (e.host == generators && e.n == n && e.curve == vt.curve_id && e.sample_hash == hash) hit = &e;
+    if (e.last_use < victim->last_use) victim = &e;
+  }
+  if (hit == nullptr) {
+    // a new key (or the same pointer with other content): remember it, drop what the slot held
+    ds.activate();
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+    victim->table.release();
+    *victim = generator_cache_entry{};
+    victim->host = generators;
+    victim->n = n;
+    victim->curve = vt.curve_id;
+    victim->sample_hash = hash;
+    victim->sightings = 1;
+    victim->last_use = ++ds.cache_clock;
+    return nullptr;
+  }
+  hit->last_use = ++ds.cache_clock;
+  hit->sightings += 1;
+  if (!hit->built) {
+    // second sighting: register the set (one more upload of the generators, once)
+    ds.activate();
+    void* d_tmp = nullptr;
+    const size_t bytes = vt.api_generator_size * n;
+    BZ_HIP_CHECK(hipMalloc(&d_tmp, bytes));
+    BZ_HIP_CHECK(hipMemcpyAsync(d_tmp, generators, bytes, hipMemcpyHostToDevice, ds.stream));
+    hit->table.build(vt, d_tmp, false, n, ds.stream);
+    BZ_HIP_CHECK(hipStreamSynchronize(ds.stream));
+    BZ_HIP_CHECK(hipFree(d_tmp));
+    hit->built = true;
+    st.cache_builds.fetch_add(1);
+  } else {
+    st.cache_hits.fetch_add(1);
+  }
+  return &hit->table;
+}
 
 //--------------------------------------------------------------------------------------------------
 // multi-device plumbing
@@ -237,7 +307,8 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   for (const auto& c : cols) {
     total_bytes += device_arena::padded(static_cast<size_t>(c.n) * c.row_stride + 32);
   }
-  const size_t gen_bytes = gens.source == generator_source::host_api
+  const size_t gen_bytes = gens.cached != nullptr ? 0
+                           : gens.source == generator_source::host_api
                                ? device_arena::padded(vt.api_generator_size * longest + 32) +
                                      device_arena::padded(vt.addend_size * (longest + 1))
                                : device_arena::padded(sizeof(ed_point) * (longest + 1)) +
@@ -260,7 +331,13 @@ u8* enqueue_commitments(api_state& st, device_state& ds, const curve_vtable& vt,
   const void* d_addends = nullptr;
   bool resident = false;
   window_table tables{};
-  if (gens.source == generator_source::host_api) {
+  if (gens.cached != nullptr) {
+    d_addends = gens.cached->rows_from(0, vt.resident_addend_size);
+    resident = true;
+    if (gens.cached->tables() != nullptr && longest <= gens.cached->shape.stride) {
+      tables = gens.cached->shape;
+    }
+  } else if (gens.source == generator_source::host_api) {
     u8* d_api = ds.io.take<u8>(vt.api_generator_size * longest + 32);
     void* prepared = ds.io.take<u8>(vt.addend_size * (longest + 1));
     d_addends = prepared;
@@ -694,14 +771,18 @@ void compute_commitments_locked(api_state& st, const curve_vtable& vt, void* com
                                 offset_generators <= st.host_generators.size() &&
                                 cc.longest <= st.host_generators.size() - offset_generators &&
                                 ds.builtin.d_addends != nullptr;
+    generator_ref call_gens = all_gens;
+    if (source == generator_source::host_api) {
+      call_gens.cached = cached_caller_generators(st, ds, vt, generators, cc.longest);
+    }
     row_pipeline_shape shape;
-    if (source == generator_source::host_api || cached_builtin) {
+    if (call_gens.cached == nullptr && (source == generator_source::host_api || cached_builtin)) {
       shape = choose_row_chunks(vt, cc.cols, cc.longest, source == generator_source::host_api);
     }
     u8* d_out = shape.chunks > 1
-                    ? enqueue_commitments_row_pipeline(st, ds, vt, cc.cols, cc.longest, all_gens,
+                    ? enqueue_commitments_row_pipeline(st, ds, vt, cc.cols, cc.longest, call_gens,
                                                        out_stride, projective_out, shape, events)
-                    : enqueue_commitments(st, ds, vt, cc.cols, cc.longest, all_gens, out_stride,
+                    : enqueue_commitments(st, ds, vt, cc.cols, cc.longest, call_gens, out_stride,
                                           projective_out, events);
     BZ_HIP_CHECK(hipMemcpyAsync(out, d_out, static_cast<size_t>(out_stride) * num_sequences,
                                 hipMemcpyDeviceToHost, ds.stream));
@@ -924,6 +1005,9 @@ int sxt_init(const struct sxt_config* config) {
     BZ_HIP_CHECK(hipSetDevice(current));
   } else {
     st->host_shards = static_cast<size_t>(env_count("BLITZAR_AMD_FORCE_SHARDS", 1));
+  }
+  if (const char* v = std::getenv("BLITZAR_AMD_GENERATOR_CACHE")) {
+    st->generator_cache = !(v[0] == '0' && v[1] == 0) && v[0] != 0;
   }
   init_host_generators(*st, config->num_precomputed_generators);
   g_state = st.release();
@@ -1499,9 +1583,25 @@ int bzamd_accumulate_form(void) {
 
 uint64_t bzamd_kernel_launch_count(void) { return g_kernel_launches.load(); }
 
+void bzamd_generator_cache_stats(uint64_t* hits, uint64_t* builds) {
+  if (hits != nullptr) *hits = g_state == nullptr ? 0 : g_state->cache_hits.load();
+  if (builds != nullptr) *builds = g_state == nullptr ? 0 : g_state->cache_builds.load();
+}
+
 int bzamd_probe_mad_rate(double target_ms, double* out) {
-  api_state& st = state();
-  if (st.backend != SXT_GPU_BACKEND || out == nullptr) return -1;
+  if (g_state == nullptr || g_state->backend != SXT_GPU_BACKEND || out == nullptr) return -1;
+  api_state& st = *g_state;
+  // the probe loads every SIMD of the CURRENT device for `target_ms`: if the backend drives that
+  // device, hold its lease so that no blocking sxt_* call is timed (or slowed) beside it
+  int device = 0;
+  BZ_HIP_CHECK(hipGetDevice(&device));
+  api_state::device_lease lease;
+  for (auto& d : st.devices) {
+    if (d->device == device) {
+      lease = st.lease(*d);
+      break;
+    }
+  }
   return msm_probe_mad_rate(target_ms, out) ? 0 : -1;
 }
 

@@ -131,6 +131,26 @@ struct current_device_guard {
   current_device_guard& operator=(const current_device_guard&) = delete;
 };
 
+// BLITZAR_AMD_GENERATOR_CACHE=1 (opt-in): a drop-in caller of sxt_*_with_generators hands the same
+// host array of generators to call after call (Proof-of-SQL commits many tables against one set) and
+// pays its upload every time -- 160 MB of PCIe per call at 2^20 curve25519 generators, what the
+// reference does too (sxt/multiexp/bucket_method/accumulation.h:68-71).  With the knob on, a device
+// remembers (host pointer, count, curve, hash of a 1-in-256 sample of the rows); the SECOND call
+// that shows the same key registers the set as a resident one (its own upload, Z = 1 addends, window
+// tables: what bzamd_generators_new_host does), and later calls whose key and sample hash still match
+// run on it and upload scalars only.  The caveat that makes it opt-in: a caller who rewrites rows the
+// sample misses, in place, under the same pointer, gets commitments to the OLD generators.
+struct generator_cache_entry {
+  const void* host = nullptr;
+  u64 n = 0;
+  unsigned curve = 0;
+  u64 sample_hash = 0;
+  u32 sightings = 0;
+  u64 last_use = 0;
+  bool built = false;
+  resident_table table;
+};
+
 struct device_state {
   // A blocking sxt_* call owns the devices it runs on for its duration: their stream pair, engine
   // context and staging arena (api_state::device_lease).  Calls on different devices run
@@ -144,12 +164,15 @@ struct device_state {
   msm_context* ctx = nullptr;
   device_arena io;                   // staging of host operands / results of the blocking calls
   resident_table builtin; // the built-in generators cached at sxt_init
+  generator_cache_entry caller_cache[2]; // BLITZAR_AMD_GENERATOR_CACHE (see above)
+  u64 cache_clock = 0;
 
   void activate() const { BZ_HIP_CHECK(hipSetDevice(device)); }
   ~device_state() {
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
     builtin.release();
+    for (auto& e : caller_cache) e.table.release();
     if (ctx != nullptr) msm_context_free(ctx);
     if (copy_stream != nullptr) (void)hipStreamDestroy(copy_stream);
     if (stream != nullptr) (void)hipStreamDestroy(stream);
@@ -228,6 +251,8 @@ struct api_state {
     return l;
   }
   size_t host_shards = 1; // SXT_CPU_BACKEND: host threads a call is split over (FORCE_SHARDS)
+  bool generator_cache = false; // BLITZAR_AMD_GENERATOR_CACHE
+  std::atomic<u64> cache_hits{0}, cache_builds{0};
   device_arena gather; // on devices[0]: partial results of the other devices (row-split calls)
   // RCCL communicators of bzamd_msm_multi_device (one per device slot, ncclCommInitAll on first
   // use); `exchange_state`: 0 = not tried, 1 = RCCL, 2 = peer copies (logical devices sharing a

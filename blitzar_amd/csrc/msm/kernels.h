@@ -49,6 +49,14 @@ constexpr u32 kReduceHeavyHeads = 16;
 constexpr u32 kReduceMaxHeavy = 8;
 constexpr u32 kAccumulateThreads = 256;
 constexpr u32 kCombineThreads = 256;
+#ifndef BZ_FRONT_PRIO
+#define BZ_FRONT_PRIO 0
+#endif
+__device__ __forceinline__ void front_priority() {
+#if BZ_FRONT_PRIO != 0
+  __builtin_amdgcn_s_setprio(BZ_FRONT_PRIO);
+#endif
+}
 
 //--------------------------------------------------------------------------------------------------
 // k_prepare_addends
@@ -78,6 +86,7 @@ template <class C>
 __global__ void __launch_bounds__(256)
     k_prepare_addends_staged(typename C::addend* __restrict__ addends,
                              const void* __restrict__ api_generators, u64 n) {
+  front_priority();
   using addend = typename C::addend;
   constexpr u32 G = static_cast<u32>(C::api_generator_size);
   constexpr u32 A = static_cast<u32>(sizeof(addend));
@@ -237,6 +246,7 @@ __global__ void __launch_bounds__(256)
     k_recode(D* __restrict__ digits, const column_desc* __restrict__ columns,
              const task_desc* __restrict__ tasks, u32 num_columns, u32 num_chunks,
              u32* __restrict__ zero, u64 zero_words) {
+  front_priority();
   // the group cursors of the sort start at zero: cleared here, by the first kernel of the call,
   // instead of by a memset (two fill kernels and two stream bubbles per call)
   for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < zero_words;
@@ -290,6 +300,7 @@ __global__ void __launch_bounds__(256)
 static __global__ void __launch_bounds__(256)
     k_recode_rows32_c16(i16* __restrict__ digits, const column_desc* __restrict__ columns,
                         const task_desc* __restrict__ tasks, u32* __restrict__ zero, u64 zero_words) {
+  front_priority();
   const u64 threads = static_cast<u64>(gridDim.x) * gridDim.y * blockDim.x;
   for (u64 i = (static_cast<u64>(blockIdx.y) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
        i < zero_words; i += threads) {
@@ -531,6 +542,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroup
                  u32* __restrict__ arrivals, u32* __restrict__ group_start,
                  u32* __restrict__ group_chunk, u32* __restrict__ bucket_count,
                  u32* __restrict__ bucket_fill, u32 stream_limit) {
+  front_priority();
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   __shared__ u32 wave_sums[kSortThreads / 64];
   __shared__ u32 wave_chunks[kSortThreads / 64];
@@ -601,6 +613,7 @@ template <bool Staged, class D>
 __global__ void __launch_bounds__(kSortThreads, 8) // <= 64 VGPRs: two workgroups per CU
     k_group_scatter(u32* __restrict__ records, u32* __restrict__ group_cursor,
                     const D* __restrict__ digits, const task_desc* __restrict__ tasks) {
+  front_priority();
   constexpr u32 V = kDigitsPerVector<D>;                   // digits per 16-byte vector: 8 or 4
   constexpr u32 H = kStagedSliceRows / (V * kSortThreads); // vectors a thread holds: 2 or 4
   static_assert(H * V * kSortThreads == kStagedSliceRows);
@@ -1138,6 +1151,7 @@ __global__ void __launch_bounds__(kGroupSortThreads, 8)
     k_task_sort(u32* __restrict__ sorted, u32* __restrict__ segment_bucket,
                 u32* __restrict__ bucket_end, const D* __restrict__ digits,
                 const task_desc* __restrict__ tasks) {
+  front_priority();
   __shared__ sort_lds lds;
   u32* cursor = lds.cursor;
   u32* staging = lds.staging;
@@ -1231,6 +1245,7 @@ static __global__ void __launch_bounds__(kGroupSortThreads, 8) // <= 64 VGPRs: f
                      u32* __restrict__ bucket_count, u32* __restrict__ bucket_fill,
                      const u32* __restrict__ big_tasks, u32* __restrict__ big_barrier,
                      u32 max_workers) {
+  front_priority();
   __shared__ sort_lds lds;
   if (blockIdx.y < num_tasks) {
     const task_desc task = tasks[blockIdx.y];
@@ -1289,7 +1304,8 @@ template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 d
   return r;
 }
 
-// wave priorities (s_setprio, 0..3) of the two tail kernels, see k_reduce
+// wave priorities (s_setprio, 0..3) of the two tail kernels, see k_reduce; BZ_FRONT_PRIO: of the
+// front kernels (conversion, recoding, the sort), 0 = the hardware default, no instruction
 #ifndef BZ_REDUCE_PRIO
 #define BZ_REDUCE_PRIO 3
 #endif

@@ -185,6 +185,7 @@ struct msm_plan {
   u32 reduce_threads = kReduceThreads;          // lanes of a k_reduce block: 256, or 64 (small tasks)
   u32 reduce_block_buckets() const { return reduce_threads << reduce_segment_log2; }
   // log2 of the buckets a k_reduce block covers (what k_horner counts a task's partials by)
+  static_assert(kReduceThreads == 256, "reduce_block_log2 counts 256-lane blocks as 2^8 lanes");
   u32 reduce_block_log2() const { return (reduce_threads == 64 ? 6 : 8) + reduce_segment_log2; }
 };
 

@@ -81,6 +81,15 @@ int bzamd_slow_instruction_fetch(void);
  *   out[3] milliseconds of load the probe ran
  * Returns 0, or -1 without the GPU backend.  bench.py normalises `roofline.alu` with it. */
 int bzamd_probe_mad_rate(double target_ms, double* out);
+/* BLITZAR_AMD_GENERATOR_CACHE=1 (read by sxt_init; off by default): the blocking
+ * sxt_*_compute_pedersen_commitments_with_generators entry points keep a caller's host generators on
+ * the device across calls.  Key = (host pointer, count, curve) + a hash of a 1-in-256 sample of the
+ * rows; the second call with the same key registers the set (one extra upload), later calls whose key
+ * and sample still match upload scalars only (the reference re-uploads on every call:
+ * sxt/multiexp/bucket_method/accumulation.h:68-71).  CAVEAT: rewriting rows the sample misses, in
+ * place, is not noticed -- hence opt-in.  Counters: calls served from the cache / sets registered. */
+void bzamd_generator_cache_stats(uint64_t* hits, uint64_t* builds);
+
 /* drop the backend singleton so that sxt_init may be called again (reference:
  * cbn::reset_backend_for_testing, cbindings/backend.cc:111) */
 void bzamd_reset_for_testing(void);

@@ -3,6 +3,7 @@
 the reference's own CPU backend (oracle/_ref) and committed as tests/golden/fullsize_golden.npz:
 
     python tests/golden/make_golden_fullsize.py          # ~15 min, ~8 GB
+    python tests/golden/make_golden_fullsize.py --only curve1_1x2^22   # add / refresh one case
 
 Inputs are rebuilt from their recipe wherever the fixture is used (they are 100 MB apiece):
   * scalars: the `std::mt19937{0}` byte stream of the reference benchmarks
@@ -33,7 +34,8 @@ from oracle import ref_oracle  # noqa: E402
 from tests import util  # noqa: E402
 
 # (curve id, columns, log2 rows)
-CASES = [(1, 1, 20), (2, 2, 20), (3, 1, 18)]
+# (the last one is BASELINE config 3's own shape: one bls12-381 column of 2^22 rows)
+CASES = [(1, 1, 20), (2, 2, 20), (3, 1, 18), (1, 1, 22)]
 DISTINCT_SEEDS = 1024
 
 
@@ -46,6 +48,29 @@ def inputs(cid, columns, log2n):
     return scalars, gens
 
 
+# rows the reference CPU backend takes in one call: its multiproduct index table counts 32-bit entries
+# (one per set scalar bit: 2^22 rows x 256 bits overflow it -- std::bad_alloc from
+# mtxpi::compute_multiexponentiation at BASELINE config 3's own shape).  A longer column is committed
+# in row chunks of this size by the reference's MSM (raw projective results) and the chunks are summed
+# with the reference's own addition and encoded by its own canonicaliser: exact group arithmetic, so
+# the bytes are those of the whole column.
+ROW_CHUNK = 1 << 20
+
+
+def reference_commit(cid, scalars, gens):
+    columns, n = scalars.shape[0], scalars.shape[1]
+    if n <= ROW_CHUNK:
+        return ref_oracle.commit(cid, [(scalars[c], False) for c in range(columns)], gens)
+    total = None
+    for lo in range(0, n, ROW_CHUNK):
+        part = ref_oracle.msm_projective(
+            cid, [(scalars[c, lo:lo + ROW_CHUNK], False) for c in range(columns)],
+            gens[lo:lo + ROW_CHUNK])
+        total = part if total is None else np.stack(
+            [ref_oracle.add_projective(cid, total[c], part[c]) for c in range(columns)])
+    return np.stack([ref_oracle.canonical(cid, total[c]) for c in range(columns)])
+
+
 def sha(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
 
@@ -53,19 +78,23 @@ def sha(a):
 def main():
     assert ref_oracle.available(), "build oracle/_ref first (python oracle/ref/build_ref.py)"
     out = {}
+    path = os.path.join(HERE, "fullsize_golden.npz")
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only is not None and os.path.exists(path):
+        out = dict(np.load(path))  # keep the other cases as they are
     for cid, columns, log2n in CASES:
+        if only is not None and only != f"curve{cid}_{columns}x2^{log2n}":
+            continue
         t0 = time.time()
         scalars, gens = inputs(cid, columns, log2n)
         t1 = time.time()
-        cols = [(scalars[c], False) for c in range(columns)]
-        got = ref_oracle.commit(cid, cols, gens)
+        got = reference_commit(cid, scalars, gens)
         print(f"curve {cid}: {columns} x 2^{log2n} rows: inputs {t1 - t0:.0f} s, reference CPU "
               f"backend {time.time() - t1:.0f} s", flush=True)
         key = f"curve{cid}_{columns}x2^{log2n}"
         out[key + "_commitments"] = got
         out[key + "_scalars_sha256"] = sha(scalars)
         out[key + "_generators_sha256"] = sha(gens)
-    path = os.path.join(HERE, "fullsize_golden.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path)} bytes)")
 

@@ -616,6 +616,13 @@ def test_planner_window_tables():
     assert all(row[:4] == [18, 15, 1, big] for row in per.tolist())
     assert int(totals[6]) == 1 and int(totals[7]) == 7 and int(totals[8]) == 1024
     assert int(totals[1]) == 8 << 17                       # one set of 2^17 buckets per column
+    # 17 bits -- the DEFAULT of Weierstrass sets of 2^20 generators and more (api/state.h): 16 slices,
+    # one task of 15 * stride + n virtual rows and 2^16 buckets per column, wide digits, 6 + 24 record bits
+    per, totals = hooks.plan_tables([big] * 8, [256] * 8, [0] * 8, big, 16, table_penalty=1.15, bits=17)
+    assert all(row[:4] == [17, 16, 1, big] for row in per.tolist())
+    assert all(int(row[4]) + (int(row[5]) << 32) == 15 * big + big for row in per.tolist())
+    assert int(totals[6]) == 1 and int(totals[7]) == 6 and int(totals[8]) == 1024
+    assert int(totals[1]) == 8 << 16
     # ... and 2^18 generators at 20 bits: 13 slices, 2^19 buckets, 9 + 22 record bits, 1024 groups
     per, totals = hooks.plan_tables([1 << 18] * 8, [256] * 8, [0] * 8, 1 << 18, 13, force=True, bits=20)
     assert all(row[:4] == [20, 13, 1, 1 << 18] for row in per.tolist())

@@ -1,5 +1,5 @@
 """Window tables of resident generator sets (msm/plan.h `window_table`): slices 2^(bits w) g_i kept
-in HBM so that all windows of a column share one bucket set, at table widths 16, 18 and 20.  The tables are built for sets of
+in HBM so that all windows of a column share one bucket set, at table widths 16, 17, 18 and 20.  The tables are built for sets of
 2^14 generators or more; BLITZAR_AMD_WINDOW_TABLE_MIN lowers that so that oracle-sized inputs take
 the merged path, and BLITZAR_AMD_FORCE_WINDOW_TABLES overrides the planner's cost model, which
 would keep such short columns on separate windows (a child process: the environment is read when
@@ -99,10 +99,12 @@ def expected(oracle, curves, n, seed):
     return want
 
 
-# bits: the window width the table is built for.  16 = int16 digits (sets below 2^18 generators);
-# 18 (what sets of 2^18 generators and more take) and 20 = the wide form: 32-bit digits, 2^17 / 2^19
-# buckets per merged column, 15 / 13 slices
+# bits: the window width the table is built for.  16 = int16 digits (the default of every set but the
+# one below); 17 = what Weierstrass sets of 2^20 generators and more take by default (api/state.h,
+# resident_table::build: 16 slices, 2^16 buckets per merged column), 18 and 20 = wider still: the wide
+# form -- 32-bit digits -- with 2^17 / 2^19 buckets per merged column and 15 / 13 slices
 @pytest.mark.parametrize("curves,n,bits", [([0], 3000, 16), ([1], 1200, 16), ([2, 3], 2000, 16),
+                                           ([0], 2000, 17), ([1], 1000, 17), ([2, 3], 1800, 17),
                                            ([0], 3000, 18), ([1], 1200, 18), ([2, 3], 2000, 18),
                                            ([0], 1500, 20), ([1], 700, 20), ([2, 3], 1000, 20)])
 def test_window_tables_match_oracle(oracle, curves, n, bits):

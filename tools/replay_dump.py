@@ -63,11 +63,20 @@ def replay(path, backend):
     gens = expand_generators(curve_id, np.fromfile(os.path.join(path, "generators.bin"), np.uint8))
     width = int(np.fromfile(os.path.join(path, "window_width.bin"), dtype=np.uint64)[0])
     lengths_path = os.path.join(path, "output_lengths.bin")
-    os.environ["BLITZAR_PARTITION_WINDOW_WIDTH"] = str(width)
     os.environ.pop("BLITZAR_DUMP_DIR", None)  # do not record the replay
     if api.load().bzamd_active_backend() == 0:
         assert api.init(backend, 0) == 0
-    handle = api.MultiexpHandle(curve_id, gens)
+    # the handle takes the recording's window width (read when it is created); the caller's own
+    # setting is put back
+    before = os.environ.get("BLITZAR_PARTITION_WINDOW_WIDTH")
+    os.environ["BLITZAR_PARTITION_WINDOW_WIDTH"] = str(width)
+    try:
+        handle = api.MultiexpHandle(curve_id, gens)
+    finally:
+        if before is None:
+            os.environ.pop("BLITZAR_PARTITION_WINDOW_WIDTH", None)
+        else:
+            os.environ["BLITZAR_PARTITION_WINDOW_WIDTH"] = before
     if os.path.exists(lengths_path):
         lengths = np.fromfile(lengths_path, dtype=np.uint32)
         got = handle.vlen_multiexponentiation(bit_table, lengths, scalars)
