@@ -277,6 +277,13 @@ template <class C, class R = C, class H = C> struct curve_tu {
         return;
       }
     }
+    if constexpr (!std::is_same_v<C, R> && R::has_batched_prepare) {
+      if (d_addends == nullptr && ctx.normalise_caller) {
+        msm_enqueue_locked<R>(ctx, d_out, out_stride, projective_out, cols, nullptr,
+                              d_api_generators, stream);
+        return;
+      }
+    }
     msm_enqueue_locked<C>(ctx, d_out, out_stride, projective_out, cols,
                           static_cast<const typename C::addend*>(d_addends), d_api_generators, stream);
   }

@@ -154,6 +154,16 @@ struct msm_context {
   // fork / join pair costs ~25 us of stream bubbles).
   hipStream_t tail = nullptr, tail2 = nullptr; // k_reduce / k_horner of a pipelined batch
   stage_mark acc_done[4], reduce_done[4], horner_done[4];
+  // `pre_horner[k]`: recorded on the k_horner stream behind its wait for reduce(k) and in front of
+  // horner(k) -- that stream runs in order, so the mark fires when horner(k - 1) AND reduce(k) are
+  // done.  The caller's stream waits for this ONE mark per batch (end of batch k: pre_horner[k - 1])
+  // instead of for horner_done[k - 2] there and for reduce_done[k - 1] in front of the next batch's
+  // front and again in front of its accumulation: every cross-stream wait is a barrier packet that
+  // costs the queue 8-12 us (round 6 timeline: 24 us between k_accumulate and the next front, 13 us
+  // in front of k_accumulate -- profiles/round6_timeline_sequence.txt).
+  stage_mark pre_horner[4];
+  u64 reduce_joined = 0; // `reduce_joined_on` has waited for the reduce of every batch below this
+  hipStream_t reduce_joined_on = nullptr;
   // Per-call window tables (plan.h, choose_call_table; built by curve_tu.h, build_call_table): the
   // 2^(c w) multiples of a call's caller generators, rebuilt by every call that wants them into this
   // grow-only block.  Only k_accumulate reads the table, so the build -- a chain of W c dependent
@@ -168,6 +178,15 @@ struct msm_context {
   bool table_pending = false;
   bool call_tables = true;
   bool table_overlap = true;
+  // curve25519, BLITZAR_AMD_NORMALISE_CALLER=1: caller generators are normalised to Z = 1 in every
+  // call (kernels.h, k_batch_*: three launches, no workgroup waits for an inversion) and the
+  // accumulation runs the 7-product loop of resident sets.  OFF by default, measured on MI355X at
+  // config 2 (profiles/round6_ab_normalise_caller.log): k_accumulate 0.618 -> 0.573 ms, but the
+  // normalisation takes 0.200 ms against the 0.066 of the plain conversion -- a lone call 1.17 ->
+  // 1.26 ms, a step in sequence 0.978 -> 1.054 -- and on the side stream beside recode + sort
+  // (BLITZAR_AMD_CALL_TABLE_OVERLAP) every memory-bound kernel of the front takes 2.5-4x as long
+  // (recode 0.018 -> 0.07, sort 0.11 -> 0.27; step 1.16).
+  bool normalise_caller = false;
   u32 force_call_table_bits = 0;
   u64 call_tables_built = 0; // (tests: bzamd_set_call_tables returns it)
   const void* call_table_rows = nullptr; // slice 0 of the table built last
@@ -239,12 +258,33 @@ struct msm_context {
   // batch k reused, so it is long done): a pipelined result is complete on the stream once two
   // further calls have been enqueued, or after a flush.  (Waiting for the previous batch here
   // would put its k_horner in front of whatever the caller enqueues next.)
+  // BLITZAR_AMD_MERGED_WAITS=1: one wait per batch (pre_horner) instead of three.  OFF: measured on
+  // one MI355X box, 4 x 300 steps each (profiles/round6_ab_merged_waits.log): the gaps shrink (24 ->
+  // 17 us behind k_accumulate, 13 -> 6.5 us in front of it) and the step does not -- 0.9701 against
+  // 0.9729 ms with the single wait: k_reduce and the sort stretch by what the gaps gave up.  The step
+  // in throughput mode is bound by the work of its stages, not by the packets between them.
+  bool merged_waits = false;
   void join_two_back(hipStream_t stream, u64 k) {
-    if (k >= 2 && (joined < k - 1 || stream != joined_on)) {
-      horner_done[(k - 2) & 3].wait(stream);
+    if (!merged_waits) {
+      if (k >= 2 && (joined < k - 1 || stream != joined_on)) {
+        horner_done[(k - 2) & 3].wait(stream);
+        joined = k - 1;
+        joined_on = stream;
+      }
+      return;
+    }
+    if (k >= 1 && (joined < k - 1 || reduce_joined < k || stream != joined_on ||
+                   stream != reduce_joined_on)) {
+      pre_horner[(k - 1) & 3].wait(stream); // horner(k - 2) and reduce(k - 1)
       joined = k - 1;
       joined_on = stream;
+      reduce_joined = k;
+      reduce_joined_on = stream;
     }
+  }
+  // has `stream` already waited for the reduce of batch `batch`?
+  bool reduce_is_joined(hipStream_t stream, u64 batch) const {
+    return reduce_joined > batch && stream == reduce_joined_on;
   }
   // make `stream` wait for every pipelined batch enqueued so far (k_horner runs on ONE stream, in
   // order, and is the last stage of a batch: the last batch's mark covers everything)
@@ -253,6 +293,8 @@ struct msm_context {
     horner_done[(seq - 1) & 3].wait(stream);
     joined = seq;
     joined_on = stream;
+    reduce_joined = seq; // (horner(k) runs behind reduce(k))
+    reduce_joined_on = stream;
   }
   char* desc_dev[2] = {nullptr, nullptr};
   size_t desc_cap[2] = {0, 0};
@@ -276,6 +318,7 @@ struct msm_context {
       acc_done[i].destroy();
       reduce_done[i].destroy();
       horner_done[i].destroy();
+      pre_horner[i].destroy();
     }
     table_fork.destroy();
     table_ready.destroy();
@@ -350,7 +393,13 @@ size_t msm_workspace_bytes(const msm_plan& plan, bool needs_addends, u32 partial
   // (the descriptors live in a block of their own: msm_context::descriptor_block)
   // what the front writes and the accumulation reads
   size_t front = 0;
-  if (needs_addends) front += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
+  if (needs_addends) {
+    front += device_arena::padded(sizeof(addend) * (plan.max_rows + 1));
+    if constexpr (C::has_batched_prepare) {
+      front += device_arena::padded(sizeof(typename C::batch_fe) *
+                                    batch_prepare_scratch_elements(plan.max_rows));
+    }
+  }
   front += device_arena::padded((plan.wide_digits ? sizeof(i32) : sizeof(i16)) * (plan.total_entries + 8));
   front += 2 * device_arena::padded(sizeof(u32) * (plan.total_entries + 8));
   front += 2 * device_arena::padded(sizeof(u32) * (plan.total_groups + 1));
@@ -579,7 +628,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
                 static_cast<u64>(num_cols), static_cast<u64>(b.partial_stride),
                 static_cast<u64>(C::curve_id), static_cast<u64>(sizeof(addend)),
                 static_cast<u64>(d_addends == nullptr),
-                static_cast<u64>(mode.piped) | static_cast<u64>(plan.wide_digits) << 1}) {
+                static_cast<u64>(mode.piped) | static_cast<u64>(plan.wide_digits) << 1 |
+                    static_cast<u64>(C::has_batched_prepare) << 2}) {
     layout = (layout ^ v) * 0x100000001b3ull;
   }
   if (ctx.any_pending() && layout != ctx.pipe_layout) ctx.join_all(stream);
@@ -628,6 +678,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       // keeps its place in the sequence: every mark of the slot points behind this launch
       ctx.acc_done[k & 3].record(hs);
       ctx.reduce_done[k & 3].record(hs);
+      ctx.pre_horner[k & 3].record(hs);
       ctx.horner_done[k & 3].record(hs);
       ctx.pipe_layout = layout;
       ctx.seq = k + 1;
@@ -636,9 +687,16 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     return;
   }
   const bool timing = ctx.timer.recording();
+  [[maybe_unused]] void* prepare_scratch = nullptr; // k_batch_* (curves that normalise per call)
   // carve the arena: the same walk for every batch of a layout, this batch's sets picked out
   {
     addend* prepared = d_addends == nullptr ? ctx.arena.take<addend>(plan.max_rows + 1) : nullptr;
+    if constexpr (C::has_batched_prepare) {
+      if (d_addends == nullptr) {
+        prepare_scratch = ctx.arena.take<typename C::batch_fe>(
+            batch_prepare_scratch_elements(plan.max_rows));
+      }
+    }
     void* digits = plan.wide_digits ? static_cast<void*>(ctx.arena.take<i32>(plan.total_entries + 8))
                                     : static_cast<void*>(ctx.arena.take<i16>(plan.total_entries + 8));
     u32* records = ctx.arena.take<u32>(plan.total_entries + 8);
@@ -691,14 +749,39 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // (Overlapping stages of ONE call was measured in round 1 and is slower: k_accumulate's waves
   // hold 480 of a SIMD's 512 VGPRs, side kernels only get slots as they retire, and everything a
   // call runs feeds its next stage.)
-  wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
+  if (!(mode.piped && k >= mode.end_sets() && ctx.reduce_is_joined(fs, k - mode.end_sets()))) {
+    wait_for(earlier(ctx.reduce_done, mode.end_sets()), fs);
+  }
   // caller generators -> addends.  (Dealing this kernel's workgroups into the group sort's launch --
   // the one HBM-saturating kernel of the front inside the LDS-bound one -- was built and measured in
   // round 3: sort + conversion 0.171 -> 0.183 ms, profiles/round3_ab_front_fusion.log; removed.)
   if (d_addends == nullptr) {
-    ctx.timer.timed(timing, 0, fs, [&] {
-      launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
-    });
+    if constexpr (C::has_batched_prepare) {
+      // Z = 1 normalisation (kernels.h, k_batch_*): only k_accumulate reads the addends, so the three
+      // launches -- the middle one a latency chain on ONE compute unit -- run on the side stream
+      // beside the recoding and the sort, like the build of a per-call window table
+      hipStream_t ps = fs;
+      if (ctx.table_overlap) {
+        ctx.make_side_stream();
+        ctx.table_fork.record(fs);
+        ctx.table_fork.wait(ctx.side);
+        ps = ctx.side;
+      }
+      ctx.timer.timed(timing, 0, ps, [&] {
+        launch_prepare_addends_split<C>(const_cast<addend*>(b.addends), d_api_generators,
+                                        plan.max_rows,
+                                        static_cast<typename C::batch_fe*>(prepare_scratch), ps);
+      });
+      g_kernel_launches += 2;
+      if (ctx.table_overlap) {
+        ctx.table_ready.record(ps);
+        ctx.table_pending = true;
+      }
+    } else {
+      ctx.timer.timed(timing, 0, fs, [&] {
+        launch_prepare_addends<C>(const_cast<addend*>(b.addends), d_api_generators, plan.max_rows, fs);
+      });
+    }
   }
   // group cursors, arrival tickets, the workers' barrier, big_tasks[0]: cleared by the recode kernel
   const u64 zero_words = plan.total_groups + 1 + num_tasks + 2;
@@ -795,7 +878,9 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   }
 
   // ---- accumulate: rewrites the bucket sums / head partials the reduce two batches ago read
-  wait_for(earlier(ctx.reduce_done, 2), as);
+  if (!(mode.piped && k >= 2 && ctx.reduce_is_joined(as, k - 2))) {
+    wait_for(earlier(ctx.reduce_done, 2), as);
+  }
   if (ctx.table_pending) {
     // the call's window table, built on the side stream beside this front
     ctx.table_ready.wait(as);
@@ -847,7 +932,10 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   if (mode.piped) ctx.reduce_done[k & 3].record(rs);
 
   // ---- horner: whole columns in one launch (the range covers every window, first and last)
-  if (mode.piped) ctx.reduce_done[k & 3].wait(hs);
+  if (mode.piped) {
+    ctx.reduce_done[k & 3].wait(hs);
+    ctx.pre_horner[k & 3].record(hs);
+  }
   ctx.timer.timed(timing, 5, hs, [&] {
     // (hundreds of columns: one-wavefront blocks, kernels.h)
     if (num_cols >= 64 && plan.max_windows <= 64) {

@@ -207,6 +207,143 @@ __global__ void __launch_bounds__(kBatchPrepareThreads, BZ_BATCH_PREPARE_WAVES)
   });
 }
 
+// The same normalisation without a workgroup waiting for its own inversion: k_prepare_addends_batched
+// has every workgroup of the launch sit through a ~50 us exponentiation at the same time (all but one
+// of its wavefronts idle), which is what made per-call normalisation lose in round 2.  Split in
+// three launches, the machine-wide part has no latency chain in it and the chain runs ONCE, on one
+// compute unit, beside whatever else the call has to do (recoding, the sort):
+//   k_batch_products   every workgroup multiplies its 1024 Z's up (lane prefixes + the LDS tree) and
+//                      writes ONE field element, the product of them all;
+//   k_batch_invert     one workgroup per 1024 of those products: the same trick one level up, one
+//                      wave-cooperative inversion per workgroup (2^20 generators: ONE workgroup);
+//   k_batch_finish     every workgroup rebuilds its prefixes and tree (3 + 1 products per generator:
+//                      cheaper than keeping 40 KiB of them per workgroup between the launches), takes
+//                      the inverse of its product from k_batch_invert, walks it down the tree and
+//                      the prefixes, and writes the Z = 1 addends.
+template <class C>
+__device__ __forceinline__ void batch_prefixes(typename C::batch_fe (&z)[kBatchPreparePoints],
+                                               typename C::batch_fe (&prefix)[kBatchPreparePoints],
+                                               const void* __restrict__ api_generators, u64 base,
+                                               u64 n, u32 tid) {
+  static_for<kBatchPreparePoints>([&](auto jc) {
+    constexpr u32 j = decltype(jc)::value;
+    const u64 i = base + static_cast<u64>(j) * kBatchPrepareThreads + tid;
+    z[j] = i < n ? C::batch_load_z(api_generators, i) : C::batch_one();
+    if constexpr (j == 0) {
+      prefix[0] = z[0];
+    } else {
+      prefix[j] = C::batch_mul(prefix[j - 1], z[j]);
+    }
+  });
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBatchPrepareThreads)
+    k_batch_products(typename C::batch_fe* __restrict__ block_products,
+                     const void* __restrict__ api_generators, u64 n) {
+  using fe = typename C::batch_fe;
+  front_priority();
+  __shared__ fe tree[2 * kBatchPrepareThreads];
+  const u32 tid = threadIdx.x;
+  const u64 base = static_cast<u64>(blockIdx.x) * kBatchPrepareThreads * kBatchPreparePoints;
+  fe z[kBatchPreparePoints], prefix[kBatchPreparePoints];
+  batch_prefixes<C>(z, prefix, api_generators, base, n, tid);
+  tree[kBatchPrepareThreads + tid] = prefix[kBatchPreparePoints - 1];
+  tree_products<C, kBatchPrepareThreads>(tree, tid);
+  if (tid == 0) block_products[blockIdx.x] = tree[1];
+}
+
+// block_inverses[b] = 1 / block_products[b], 1024 per workgroup with one shared inversion
+template <class C>
+__global__ void __launch_bounds__(kBatchPrepareThreads)
+    k_batch_invert(typename C::batch_fe* __restrict__ block_inverses,
+                   const typename C::batch_fe* __restrict__ block_products, u32 num_blocks) {
+  using fe = typename C::batch_fe;
+  __builtin_amdgcn_s_setprio(3); // a latency chain on one compute unit, beside the call's front
+  __shared__ fe tree[2 * kBatchPrepareThreads];
+  const u32 tid = threadIdx.x;
+  const u32 base = blockIdx.x * kBatchPrepareThreads * kBatchPreparePoints;
+  fe z[kBatchPreparePoints], prefix[kBatchPreparePoints];
+  static_for<kBatchPreparePoints>([&](auto jc) {
+    constexpr u32 j = decltype(jc)::value;
+    const u32 i = base + j * kBatchPrepareThreads + tid;
+    z[j] = i < num_blocks ? block_products[i] : C::batch_one();
+    if constexpr (j == 0) {
+      prefix[0] = z[0];
+    } else {
+      prefix[j] = C::batch_mul(prefix[j - 1], z[j]);
+    }
+  });
+  tree[kBatchPrepareThreads + tid] = prefix[kBatchPreparePoints - 1];
+  tree_products<C, kBatchPrepareThreads>(tree, tid);
+  if (tid < 64) {
+    const fe inv = C::batch_wave_invert(tree[1]);
+    if (tid == 0) tree[1] = inv;
+  }
+  tree_inverses<C, kBatchPrepareThreads>(tree, tid);
+  fe inv = tree[kBatchPrepareThreads + tid];
+  static_for<kBatchPreparePoints>([&](auto jc) {
+    constexpr u32 j = kBatchPreparePoints - 1 - decltype(jc)::value;
+    fe zinv = inv;
+    if constexpr (j != 0) {
+      zinv = C::batch_mul(inv, prefix[j - 1]);
+      inv = C::batch_mul(inv, z[j]);
+    }
+    const u32 i = base + j * kBatchPrepareThreads + tid;
+    if (i < num_blocks) block_inverses[i] = zinv;
+  });
+}
+
+template <class C>
+__global__ void __launch_bounds__(kBatchPrepareThreads)
+    k_batch_finish(typename C::addend* __restrict__ addends,
+                   const typename C::batch_fe* __restrict__ block_inverses,
+                   const void* __restrict__ api_generators, u64 n) {
+  using fe = typename C::batch_fe;
+  front_priority();
+  __shared__ fe tree[2 * kBatchPrepareThreads];
+  const u32 tid = threadIdx.x;
+  const u64 base = static_cast<u64>(blockIdx.x) * kBatchPrepareThreads * kBatchPreparePoints;
+  fe z[kBatchPreparePoints], prefix[kBatchPreparePoints];
+  batch_prefixes<C>(z, prefix, api_generators, base, n, tid);
+  tree[kBatchPrepareThreads + tid] = prefix[kBatchPreparePoints - 1];
+  tree_products<C, kBatchPrepareThreads>(tree, tid);
+  if (tid == 0) tree[1] = block_inverses[blockIdx.x];
+  tree_inverses<C, kBatchPrepareThreads>(tree, tid);
+  fe inv = tree[kBatchPrepareThreads + tid];
+  static_for<kBatchPreparePoints>([&](auto jc) {
+    constexpr u32 j = kBatchPreparePoints - 1 - decltype(jc)::value;
+    fe zinv = inv;
+    if constexpr (j != 0) {
+      zinv = C::batch_mul(inv, prefix[j - 1]);
+      inv = C::batch_mul(inv, z[j]);
+    }
+    const u64 i = base + static_cast<u64>(j) * kBatchPrepareThreads + tid;
+    if (i < n) addends[i] = C::batch_make_addend(api_generators, i, zinv);
+  });
+}
+
+// field elements of scratch the three launches need for n generators (products | inverses)
+inline size_t batch_prepare_scratch_elements(u64 n) {
+  const u64 per_block = static_cast<u64>(kBatchPrepareThreads) * kBatchPreparePoints;
+  return 2 * static_cast<size_t>((n + per_block - 1) / per_block) + 2;
+}
+template <class C>
+void launch_prepare_addends_split(typename C::addend* d_addends, const void* d_api_generators, u64 n,
+                                  typename C::batch_fe* d_scratch, hipStream_t stream) {
+  if (n == 0) return;
+  const u64 per_block = static_cast<u64>(kBatchPrepareThreads) * kBatchPreparePoints;
+  const u32 blocks = ceil_div_u32(n, per_block);
+  typename C::batch_fe* products = d_scratch;
+  typename C::batch_fe* inverses = d_scratch + blocks + 1;
+  hipLaunchKernelGGL((k_batch_products<C>), dim3(blocks), dim3(kBatchPrepareThreads), 0, stream,
+                     products, d_api_generators, n);
+  hipLaunchKernelGGL((k_batch_invert<C>), dim3(ceil_div_u32(blocks, per_block)),
+                     dim3(kBatchPrepareThreads), 0, stream, inverses, products, blocks);
+  hipLaunchKernelGGL((k_batch_finish<C>), dim3(blocks), dim3(kBatchPrepareThreads), 0, stream,
+                     d_addends, inverses, d_api_generators, n);
+}
+
 #ifndef BZ_PREPARE_STAGED
 #define BZ_PREPARE_STAGED 1
 #endif
