@@ -9,7 +9,7 @@ for spec in "$@"; do
   envs=${spec%@*}; lib=${spec#*@}
   [ -z "$lib" ] && lib=blitzar_amd/lib/libblitzar_amd.so
   echo "== $spec" >> $OUT
-  env $(echo $envs | tr ',' ' ') BLITZAR_AMD_LIB=$PWD/$lib timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-configs 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms %.4f' % d['ms_per_step'], d['stage_ms'], '| resident %.4f' % d['resident_generators_ms_per_step'], d.get('resident_generators_stage_ms'))" >> $OUT
+  env $(echo $envs | tr ',' ' ') BLITZAR_AMD_LIB=$PWD/$lib timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms %.4f' % d['ms_per_step'], d.get('stage_ms'), '| resident %.4f' % d.get('resident_generators_ms_per_step', 0))" >> $OUT
 done
 done
 cat $OUT

@@ -6,7 +6,9 @@
 #   tests       python -m pytest tests -m gpu -x -q
 #   tests:<k>   the same with -k <k>
 #   bench       python bench.py (the driver's default line)            -> bench.json
-#   bench-quick python bench.py --no-configs --skip-headline-check     -> bench_quick.json
+#   bench-quick python bench.py --skip-headline-check                  -> bench_quick.json
+#   bench-detail python bench.py --detail (configs 1/3/4/5, trace, host API) -> bench_full*.json
+#   profile-headline  tools/prof/run_pmc.sh: the same four passes of the driver's own command
 #   profile     tools/prof/run_pmc_configs.sh: rocprofv3 --kernel-trace --stats + three --pmc passes
 #               (SQ_*, FETCH_SIZE, WRITE_SIZE; no tracing beside counters) -> gpurun_out/prof_<tag>/
 #   ab:<spec-file>   tools/prof/ab_pipeline.sh over the lines of <spec-file> ("<bench args> -- <specs>")
@@ -30,10 +32,16 @@ for step in "$@"; do
       timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "${step#tests:}" > "$OUT/gputests_k.log" 2>&1
       tail -3 "$OUT/gputests_k.log" | tee -a "$OUT/session.log" ;;
     bench)
-      timeout -k 10 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+      timeout -k 10 400 python bench.py --detail-file "$OUT/bench_detail.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
       echo "rc=$? $(wc -c < "$OUT/bench.json") bytes" | tee -a "$OUT/session.log" ;;
+    bench-detail)
+      timeout -k 10 900 python bench.py --detail --detail-file "$OUT/bench_full_detail.json" > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"
+      echo "rc=$? $(wc -c < "$OUT/bench_full_detail.json") bytes of detail" | tee -a "$OUT/session.log" ;;
+    profile-headline)
+      bash tools/prof/run_pmc.sh "${TAG}_headline" > "$OUT/profile_headline.log" 2>&1
+      echo "rc=$?" | tee -a "$OUT/session.log" ;;
     bench-quick)
-      timeout 600 python bench.py --no-configs --skip-headline-check > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
+      timeout 600 python bench.py --skip-headline-check > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
       echo "rc=$?" | tee -a "$OUT/session.log" ;;
     profile)
       # rocprofv3 --kernel-trace --stats + three --pmc passes of bench.py with its configs legs
