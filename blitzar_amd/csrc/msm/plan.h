@@ -42,10 +42,18 @@ constexpr u32 kSegmentLog2Min = 3;
 // bucket_method2 regime) chose 128 entries per lane from its 1.2e8 entries and ran every task on HALF
 // a wavefront -- k_accumulate 10.8 ms against 5.7 ms at 32 entries per lane
 // (profiles/round5_ab_wide_tables_and_short_columns.log).  At least 128 lanes per task where the rows allow it.
+// A SHORT launch (a lone column of 2^12 .. 2^17 rows) cannot fill the machine at 32 entries per lane:
+// 2^14 rows x 26 windows are 13 K lanes -- a fifth of a wavefront per SIMD, each walking 32 dependent
+// additions -- so k_accumulate is a latency chain (0.10 ms at 2^14 rows, the price of 3 M additions,
+// for 0.4 M).  While the launch has less than one wavefront per SIMD (kSegmentLatencyLanes), shorter
+// segments, down to 8 entries: the chain shortens in proportion and the extra head partials are
+// additions k_reduce has idle lanes for.
+constexpr u64 kSegmentLatencyLanes = u64{1} << 16;
 inline u32 choose_segment_log2(u64 total_entries, u64 task_rows = ~u64{0}) {
   u32 s = kSegmentLog2;
   while (s < kSegmentLog2Max && (total_entries >> (s + 1)) >= kSegmentFillLanes) ++s;
   while (s > kSegmentLog2Min && (task_rows >> s) < 128) --s;
+  while (s > kSegmentLog2Min && (total_entries >> s) < kSegmentLatencyLanes) --s;
   return s;
 }
 constexpr u32 kStagedSliceRows = 1u << 14; // rows per partition workgroup: staged in LDS / direct

@@ -208,7 +208,7 @@ def test_planner_invariants():
     # narrow columns: 256 (1 byte) or 1024 (4 bytes) buckets per task spread over the 256 lanes
     # of their one reduce block, down to one bucket per lane
     _, totals = hooks.plan([1 << 20], [8], [0])
-    assert totals[6:].tolist() == [5, 0]
+    assert totals[6:].tolist() == [4, 0]     # (2^20 entries: 16 per lane fill every SIMD, below)
     _, totals = hooks.plan([1 << 20], [32], [0])
     assert totals[6:].tolist() == [5, 1]     # (a lone launch of few buckets: two per lane, below)
     # a LONE short launch (<= 2^18 buckets in all) takes two buckets per reduce lane -- k_reduce is the
@@ -217,6 +217,9 @@ def test_planner_invariants():
     assert totals[7] == 1
     _, totals = hooks.plan([1 << 16], [256], [0], in_sequence=True)
     assert totals[7] == 3
+    # ... and a short launch cannot fill the machine at 32 entries per accumulation lane: fewer, down
+    # to 8, while it has less than a wavefront per SIMD (2^14 rows: k_accumulate 0.10 -> 0.04 ms lone)
+    assert [int(hooks.plan([1 << k], [256], [0])[1][6]) for k in (12, 14, 16, 18, 20)] == [3, 3, 4, 5, 5]
     # many short columns (the reference's bucket_method2 regime): entries per accumulation lane follow
     # the rows of a task (4096 rows: 128 lanes x 32 entries, never half a wavefront of 128-entry lanes),
     # and the 256 buckets of a task go to 64 reduce lanes x 4
