@@ -186,6 +186,7 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_OVERLAP_TAILS", ctx->overlap_tails);
   flag("BLITZAR_AMD_CALL_TABLES", ctx->call_tables);
   flag("BLITZAR_AMD_CALL_TABLE_OVERLAP", ctx->table_overlap);
+  flag("BLITZAR_AMD_CALL_TABLE_WAVE_CHAIN", ctx->wave_chain);
   flag("BLITZAR_AMD_NORMALISE_CALLER", ctx->normalise_caller);
   flag("BLITZAR_AMD_MERGED_WAITS", ctx->merged_waits);
   if (const char* v = std::getenv("BLITZAR_AMD_CALL_TABLE_BITS")) {

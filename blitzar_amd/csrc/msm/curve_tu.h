@@ -83,6 +83,15 @@ __global__ void __launch_bounds__(256)
 // every slice in ONE launch -- a lane walks its generator's whole chain of doublings (the chain is
 // what the build costs: one-wavefront blocks spread the few lanes of a short generator set over as
 // many compute units as there are) -- rows between the set's end and the slice's are identities.
+// rows up to which the chain runs with a wavefront per generator.  Measured on MI355X, 1024 columns x
+// 256 / 1024 / 4096 rows, a lane per generator -> a wavefront per generator, ms per call
+// (profiles/round6_ab_wave_chain.log): curve25519 1.04 -> 0.77 / 1.77 -> 1.50 / 4.89 -> 5.00, bn254
+// 2.31 -> 1.69 / 3.92 -> 3.38 / 8.99 -> 9.33, bls12-381 4.79 -> 3.08 / 9.36 -> 7.60 / 21.5 -> 20.2: at 4096
+// rows the lane form hides behind recode + sort anyway and 4096 chain wavefronts get in their way
+// (recode 0.12 -> 0.24 ms), except on bls12-381, whose doubling is three times as long.
+template <class R> constexpr u64 wave_chain_max_rows() {
+  return sizeof(typename R::point) > 160 ? 4096 : 2048; // (bls12-381: 3 x 14 limbs = 168 bytes)
+}
 template <class R>
 __global__ void __launch_bounds__(64)
     k_chain_points(typename R::point* __restrict__ points, const void* __restrict__ api_generators,
@@ -94,6 +103,26 @@ __global__ void __launch_bounds__(64)
     points[static_cast<u64>(w) * stride + i] = p;
     if (w + 1 < windows && i < n) p = R::dbl_n(p, bits);
   }
+}
+
+// The same chain with ONE WAVEFRONT per generator (R::wave_chain: the point spread over the lanes,
+// curve/ed16_wave.h, curve/sw_wave.h): for the short generator sets the regime is about -- a few
+// thousand generators -- a lane per generator leaves the machine to 64 wavefronts that each walk
+// ~256 dependent doublings alone (0.35 ms at 256 curve25519 generators, a third of the whole call).
+template <class R>
+__global__ void __launch_bounds__(64)
+    k_chain_points_wave(typename R::point* __restrict__ points,
+                        const void* __restrict__ api_generators, u64 n, u64 stride, u32 windows,
+                        u32 bits) {
+  const u64 i = blockIdx.x;
+  if (i >= n) {
+    if (threadIdx.x < windows) points[static_cast<u64>(threadIdx.x) * stride + i] = R::identity();
+    for (u32 w = 64 + threadIdx.x; w < windows; w += 64) {
+      points[static_cast<u64>(w) * stride + i] = R::identity();
+    }
+    return;
+  }
+  R::wave_chain(points + i, stride, R::point_from_api_generator(api_generators, i), windows, bits);
 }
 
 // addends[i] = the affine (Z = 1) addend of points[i]; a workgroup's points share one inversion
@@ -218,8 +247,13 @@ template <class C, class R = C, class H = C> struct curve_tu {
       ctx.table_fork.wait(ctx.side);
       bs = ctx.side;
     }
-    hipLaunchKernelGGL((k_chain_points<R>), dim3(ceil_div_u32(t.stride, 64)), dim3(64), 0, bs, points,
-                       d_api_generators, n, t.stride, t.windows, static_cast<int>(t.bits));
+    if (t.stride <= wave_chain_max_rows<R>() && ctx.wave_chain) {
+      hipLaunchKernelGGL((k_chain_points_wave<R>), dim3(static_cast<u32>(t.stride)), dim3(64), 0, bs,
+                         points, d_api_generators, n, t.stride, t.windows, t.bits);
+    } else {
+      hipLaunchKernelGGL((k_chain_points<R>), dim3(ceil_div_u32(t.stride, 64)), dim3(64), 0, bs,
+                         points, d_api_generators, n, t.stride, t.windows, static_cast<int>(t.bits));
+    }
     hipLaunchKernelGGL((k_points_to_addends<R>),
                        dim3(ceil_div_u32(rows, 256ull * R::batch_points_per_lane)), dim3(256), 0, bs,
                        table, points, rows);

@@ -178,6 +178,7 @@ struct msm_context {
   bool table_pending = false;
   bool call_tables = true;
   bool table_overlap = true;
+  bool wave_chain = true; // BLITZAR_AMD_CALL_TABLE_WAVE_CHAIN=0: a lane per generator whatever the set's size
   // curve25519, BLITZAR_AMD_NORMALISE_CALLER=1: caller generators are normalised to Z = 1 in every
   // call (kernels.h, k_batch_*: three launches, no workgroup waits for an inversion) and the
   // accumulation runs the 7-product loop of resident sets.  OFF by default, measured on MI355X at
