@@ -108,6 +108,8 @@ def load():
     lib.bzamd_pipeline_flush.restype = None
     lib.bzamd_stage_timing_begin_masked.argtypes = [u64, u32]
     lib.bzamd_stage_timing_begin_masked.restype = None
+    lib.bzamd_stage_timing_begin_sampled.argtypes = [u64, u32, u32]
+    lib.bzamd_stage_timing_begin_sampled.restype = None
     lib.bzamd_stage_timing_collect.argtypes = [ctypes.POINTER(ctypes.c_double)]
     lib.bzamd_stage_timing_collect.restype = ctypes.c_uint64
     lib.bzamd_msm_device.argtypes = [cu, vp, u32, ctypes.POINTER(sxt_sequence_descriptor), vp, vp]

@@ -1626,6 +1626,12 @@ void bzamd_stage_timing_begin_masked(uint64_t max_calls, uint32_t stage_mask) {
   msm_context_timing_begin(st.context_for_current_device(), max_calls, stage_mask);
 }
 
+void bzamd_stage_timing_begin_sampled(uint64_t max_calls, uint32_t stage_mask, uint32_t sample_every) {
+  api_state& st = state();
+  BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "stage timing needs the GPU backend");
+  msm_context_timing_begin(st.context_for_current_device(), max_calls, stage_mask, sample_every);
+}
+
 uint64_t bzamd_stage_timing_collect(double* out_ms) {
   api_state& st = state();
   BZ_RELEASE_ASSERT(st.backend == SXT_GPU_BACKEND, "stage timing needs the GPU backend");

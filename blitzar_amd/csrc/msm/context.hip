@@ -252,9 +252,10 @@ void msm_context_join_tail(msm_context* ctx, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->join_all(stream);
 }
-void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask) {
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask,
+                              size_t sample_every) {
   std::lock_guard<std::mutex> lock(ctx->mu);
-  ctx->timer.begin(max_calls, stage_mask & 0x3f);
+  ctx->timer.begin(max_calls, stage_mask & 0x3f, sample_every);
 }
 size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]) {
   std::lock_guard<std::mutex> lock(ctx->mu);

@@ -114,7 +114,9 @@ void msm_context_set_segments(msm_context* ctx, u32 log2_entries_per_accumulate_
                               u32 log2_buckets_per_reduce_lane);
 // per-stage HIP-event timing of the next `max_calls` MSM calls on this context
 // (`stage_mask`: bit s set = record stage s; every recorded stage costs an event pair per call)
-void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask = 0x3f);
+// `sample_every`: record one MSM batch in this many (the returned count is of RECORDED batches)
+void msm_context_timing_begin(msm_context* ctx, size_t max_calls, unsigned stage_mask = 0x3f,
+                              size_t sample_every = 1);
 // accumulated ms per stage {prepare, recode, sort, accumulate, reduce, combine}; returns #calls
 size_t msm_context_timing_collect(msm_context* ctx, double out_ms[6]);
 } // namespace bz

@@ -29,15 +29,24 @@ struct stage_timer {
   size_t capacity_calls = 0;
 
   unsigned stage_mask = 0x3f; // bit s: record stage s (an event pair costs two stream bubbles)
+  // record one batch in `every` (a sample of the launches: every recorded stage is an event pair,
+  // two stream bubbles); `calls` counts the batches recorded
+  size_t every = 1, seen = 0;
 
-  void begin(size_t max_calls, unsigned mask = 0x3f) {
+  void begin(size_t max_calls, unsigned mask = 0x3f, size_t sample_every = 1) {
     release();
     capacity_calls = max_calls;
     calls = 0;
     stage_mask = mask;
+    every = sample_every == 0 ? 1 : sample_every;
+    seen = 0;
     enabled = true;
   }
-  bool recording() const { return enabled && calls < capacity_calls; }
+  // asked once per batch: is this one recorded?
+  bool recording() {
+    if (!enabled || calls >= capacity_calls) return false;
+    return seen++ % every == 0;
+  }
   // bracket `launch()` with an event pair on `stream`
   template <class F> void timed(bool on, int stage, hipStream_t stream, F&& launch) {
     if (!on || ((stage_mask >> stage) & 1) == 0) {

@@ -128,6 +128,10 @@ void bzamd_set_segments(uint32_t log2_entries_per_accumulate_lane,
  * `stage_mask` (bit 3 = accumulate), the others read 0. */
 void bzamd_stage_timing_begin(uint64_t max_calls);
 void bzamd_stage_timing_begin_masked(uint64_t max_calls, uint32_t stage_mask);
+/* ... recording one MSM in `sample_every` only (an event pair costs the stream two bubbles per
+ * recorded stage: a sample keeps a timed region honest); `max_calls` and the count
+ * bzamd_stage_timing_collect returns are then of RECORDED calls */
+void bzamd_stage_timing_begin_sampled(uint64_t max_calls, uint32_t stage_mask, uint32_t sample_every);
 uint64_t bzamd_stage_timing_collect(double* out_ms);
 
 /* Throughput mode for a sequence of device-resident MSM calls.  A call with few columns is four

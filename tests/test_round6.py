@@ -1,0 +1,45 @@
+"""Round-6 additions that have no file of their own: stage timing on a SAMPLE of the calls (what
+bench.py's timed region uses: an event pair around one k_accumulate in four), and the planner's
+choice of accumulation segments for short launches."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import hooks, util
+
+
+def test_short_launches_take_short_segments():
+    """below one wavefront per SIMD (2^16 lanes) a launch takes fewer entries per lane, down to 8:
+    k_accumulate is then a chain of that many dependent additions (2^14 rows: 0.10 -> 0.04 ms)"""
+    seg = lambda ns, bits: int(hooks.plan(ns, bits, [0] * len(ns))[1][6])   # noqa: E731
+    assert [seg([1 << k], [256]) for k in (10, 12, 14, 16, 17, 18, 20)] == [3, 3, 3, 4, 5, 5, 5]
+    assert [seg([1 << k], [8]) for k in (12, 16, 18, 20, 22)] == [3, 3, 3, 4, 5]
+    # the rule looks at the LAUNCH: ten such columns fill the machine at 32 entries per lane
+    assert seg([1 << 16] * 10, [256] * 10) == 5
+
+
+@pytest.mark.gpu
+def test_stage_timing_on_a_sample_of_the_calls(gpu_backend, oracle):
+    import torch
+    api = gpu_backend
+    lib = api.load()
+    n = 5000
+    rng = np.random.default_rng(6)
+    gens = util.generators_for(0, n)
+    g = torch.from_numpy(np.ascontiguousarray(util.api_generators(0, gens))).cuda()
+    col = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d_col = torch.from_numpy(col).cuda()
+    desc = (api.sxt_sequence_descriptor * 1)()
+    desc[0] = api.sxt_sequence_descriptor(32, n, d_col.data_ptr(), 0)
+    out = torch.zeros((1, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    lib.bzamd_stage_timing_begin_sampled(100, 1 << 3, 4)       # accumulate only, one call in four
+    for _ in range(10):
+        lib.bzamd_msm_device(0, ctypes.c_void_p(out.data_ptr()), 1, desc,
+                             ctypes.c_void_p(g.data_ptr()), None)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_double * 6)()
+    assert lib.bzamd_stage_timing_collect(ms) == 3             # calls 0, 4, 8
+    assert ms[3] > 0 and all(ms[i] == 0 for i in (0, 1, 2, 4, 5))
+    assert np.array_equal(out.cpu().numpy(), oracle.commit(0, [(col, False)], gens))
