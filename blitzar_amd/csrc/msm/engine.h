@@ -811,6 +811,11 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // 0.157 ms chunked, profiles/round4_ab_sort_stream_limit.log); in a short launch there is ONE --
   // the top window's 2^16 records in a handful of buckets -- and eleven serial rounds of a single
   // workgroup are most of the sort (2^16 rows: 0.090 ms): chunks over the workers instead.
+  // (The chunked path's workers spin at a barrier inside the launch, so all of them must become
+  // resident: `workers` below is bounded by the stream's compute units.  Work of OTHER streams that
+  // holds wave slots delays them until its workgroups retire -- it cannot hang them, nothing it runs
+  // waits for this launch: tests/test_round6.py commits 2^16-row columns beside 1.5 s of a kernel
+  // that fills every SIMD.)
   const u32 stream_limit =
       plan.total_entries <= (u64{1} << 22) ? kLocalSortCapacity : kStreamedSortRecords;
   // every task is ONE bucket group of at most an LDS stage's worth of rows (hundreds of short columns):
