@@ -165,6 +165,19 @@ BZ_HD ed29_point add_cached_presigned(const ed29_point& p, const ed29_cached& q,
   return r;
 }
 
+// identity + q (q.YpX / q.YmX already exchanged when `negate`, as add_cached_presigned takes them)
+// without an addition: (2X : 2Y : 2Z : 2T) with 2T = (2dT) / d -- one field product instead of
+// eight.  k_accumulate's first entry of a segment: every lane of the wavefront holds the identity
+// there.  All coordinates B ~ 1.
+BZ_HD ed29_point from_cached_presigned(const ed29_cached& q, bool negate) {
+  ed29_point r;
+  r.X = f29::weak_reduce(f29::sub(q.YpX, q.YmX));                     // B 3 -> 1
+  r.Y = f29::weak_reduce(f29::add(q.YpX, q.YmX));                     // B 2 -> 1
+  r.Z = f29::weak_reduce(f29::add(q.Z, q.Z));                         // B 2 -> 1
+  r.T = f29::mul(f29::cneg_xad(q.T2d, negate), f29::const_dinv());    // 2 * 1
+  return r;
+}
+
 BZ_HD ed29_point add(const ed29_point& p, const ed29_point& q) {
   return add_cached(p, to_cached(q), false);
 }
@@ -199,6 +212,19 @@ BZ_HD ed29_point add_niels(const ed29_point& p, const ed29_niels& q, bool negate
   r.Y = f29::mul(ey, ez);
   r.Z = f29::mul(ez, et);
   r.T = f29::mul(ex, ey);
+  return r;
+}
+
+// identity + q (q negated when `negate`) for a Z = 1 addend: (2x : 2y : 2 : 2xy)
+BZ_HD ed29_point from_niels(const ed29_niels& q, bool negate) {
+  const fe29 qa = f29::select(q.YpX, q.YmX, negate);
+  const fe29 qb = f29::select(q.YmX, q.YpX, negate);
+  ed29_point r;
+  r.X = f29::weak_reduce(f29::sub(qa, qb));
+  r.Y = f29::weak_reduce(f29::add(qa, qb));
+  r.Z = f29::zero();
+  r.Z.v[0] = 2;
+  r.T = f29::mul(f29::cneg_xad(q.T2d, negate), f29::const_dinv());
   return r;
 }
 

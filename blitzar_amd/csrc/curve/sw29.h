@@ -144,7 +144,8 @@ template <class P> struct sw29 {
   //     = 3.55, Z3 < (15.45 * 5.02 + 3.09 * 5.16) / 169 + 1 = 1.56;
   //   bls12-381 (|3b| = 12, max_v 2520), invariant (2, 2, 1.1): no reduce -- u2 < 13.2, u3 < 36.1,
   //     X3 < 1.15, Y3 < 1.14, Z3 < 1.03;
-  //   grumpkin (|3b| = 51, max_v 169), invariant (1.5, 1.5, 1.5): one reduce per product by 51
+  //   grumpkin (|3b| = 51, max_v 169), invariant (1.5, 2, 1.5) (V_Y = 2 only on entry, for a negated
+  //     affine point lifted by lift_acc): one reduce per product by 51
   //     instead of three -- 51 Z1 < 76.5 and 51 (x2 Z1 + X1) < 128.1 both fit below max_v p, so
   //     u2, u3 < 4 after one reduce: X3 < 1.21, Y3 < 1.37, Z3 < 1.23.
   // Every output also satisfies the general contract (normalised, V < 6).  Host builds with
@@ -176,6 +177,14 @@ template <class P> struct sw29 {
     t0 = F::add(F::add(t0, t0), t0);                                         // B 3
     const point r =
         finish<Fast, P::acc_minus_k>(t0, t1, mul_b3_acc(p.Z), t3, t4, mul_b3_acc(y3));
+    check_acc_invariant(r);
+    return r;
+  }
+
+  // identity + q (q negated when `negate`; not the identity) as an accumulator of add_mixed_acc:
+  // the affine point with Z = 1, inside the invariant (V_X <= 1, V_Y < 2, V_Z <= 1)
+  BZ_HD static point lift_acc(const affine& q, bool negate) {
+    const point r{q.x, F::select(q.y, F::norm(F::template neg<2>(q.y)), negate), F::one()};
     check_acc_invariant(r);
     return r;
   }
@@ -315,7 +324,7 @@ struct grumpkin_29_params {
   static constexpr bool b3_negative = true;
   static constexpr bool acc_reduce_b3 = true;
   static constexpr int acc_minus_k = 8;
-  static constexpr double acc_vx = 1.5, acc_vy = 1.5, acc_vz = 1.5;
+  static constexpr double acc_vx = 1.5, acc_vy = 2, acc_vz = 1.5;
 };
 struct bls12_381_g1_28_params {
   using F = bls12_381_fp28;

@@ -343,6 +343,7 @@ BZ_HD fe29 pow22523(const fe29& z) {
 
 // curve constants, converted from the canonical radix-2^51 values of field/f51.h
 BZ_HD fe29 const_2d() { return from_fe51(f51::const_2d()); }
+BZ_HD fe29 const_dinv() { return from_fe51(f51::const_dinv()); }
 BZ_HD fe29 const_sqrtm1() { return from_fe51(f51::const_sqrtm1()); }
 BZ_HD fe29 const_invsqrtamd() { return from_fe51(f51::const_invsqrtamd()); }
 } // namespace f29

@@ -249,6 +249,11 @@ BZ_HD fe51 const_2d() {
   return {{1859910466990425ULL, 932731440258426ULL, 1072319116312658ULL, 1815898335770999ULL,
            633789495995903ULL}};
 }
+// 1 / d (the extended coordinate 2T of a cached addend is its 2dT times this)
+BZ_HD fe51 const_dinv() {
+  return {{266592072628291ULL, 853561038980284ULL, 1943101592401754ULL, 2007251003935334ULL,
+           1135829554646364ULL}};
+}
 BZ_HD fe51 const_sqrtm1() {
   return {{1718705420411056ULL, 234908883556509ULL, 2233514472574048ULL, 2117202627021982ULL,
            765476049583133ULL}};

@@ -80,6 +80,11 @@ struct ed25519_msm {
   BZ_HD static void accumulate_gathered(point& acc, const operand& q, bool negate) {
     acc = ed29::add_cached_presigned(acc, q, negate);
   }
+  // identity + (+-q) of a segment's first entry: loaded, not added (k_accumulate)
+  static constexpr bool first_pinned = true; // (see k_accumulate)
+  BZ_HD static point first_gathered(const operand& q, bool negate) {
+    return ed29::from_cached_presigned(q, negate);
+  }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     return ed29::pack(ed29::cached_from_ed(static_cast<const ed_point*>(api_generators)[i]));
   }
@@ -213,6 +218,7 @@ struct ed25519_niels_msm : ed25519_msm {
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     acc = ed29::add_niels(acc, q, negate);
   }
+  BZ_HD static point first(const addend& q, bool negate) { return ed29::from_niels(q, negate); }
   static constexpr bool has_signed_gather = false; // 36-byte limb pieces: no aligned exchange
   // an accumulated entry against Z = 1 addends relative to the per-call (Y+X, Y-X, Z, 2dT) form
   // (7 of 8 field products, nothing to unpack: plan.h, choose_call_table)
@@ -421,6 +427,12 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   BZ_HD static void accumulate(point& acc, const operand& q, bool negate) {
     if (q.nonzero == 0) return;
     acc = G29::template add_mixed_acc<accumulate_pinned>(acc, q.a, negate);
+  }
+  // identity + (+-q) of a segment's first entry: the affine point itself (k_accumulate)
+  static constexpr bool first_pinned = false;
+  BZ_HD static point first(const operand& q, bool negate) {
+    if (q.nonzero == 0) return G29::identity();
+    return G29::lift_acc(q.a, negate);
   }
   BZ_HD static addend make_addend(const void* api_generators, u64 i) {
     const api_affine& g = static_cast<const api_affine*>(api_generators)[i];

@@ -688,7 +688,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
       // keeps its place in the sequence: every mark of the slot points behind this launch
       ctx.acc_done[k & 3].record(hs);
       ctx.reduce_done[k & 3].record(hs);
-      ctx.pre_horner[k & 3].record(hs);
+      if (ctx.merged_waits) ctx.pre_horner[k & 3].record(hs);
       ctx.horner_done[k & 3].record(hs);
       ctx.pipe_layout = layout;
       ctx.seq = k + 1;
@@ -949,7 +949,7 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
   // ---- horner: whole columns in one launch (the range covers every window, first and last)
   if (mode.piped) {
     ctx.reduce_done[k & 3].wait(hs);
-    ctx.pre_horner[k & 3].record(hs);
+    if (ctx.merged_waits) ctx.pre_horner[k & 3].record(hs);
   }
   ctx.timer.timed(timing, 5, hs, [&] {
     // (hundreds of columns: one-wavefront blocks, kernels.h)

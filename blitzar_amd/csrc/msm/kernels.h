@@ -1509,7 +1509,37 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     }
   };
   typename C::addend staged = gather(e_cur);
-  for (u32 i = lo; i < hi; ++i) {
+  // The first entry of a segment meets the identity in every lane of the wavefront (and never a
+  // bucket boundary: `b` is the bucket that holds entry `lo`), so it is loaded, not added:
+  // curve25519 one field product instead of eight, the Weierstrass curves none (C::first).
+  // BZ_ACCUMULATE_PEEL=0 keeps the uniform loop (A/B).
+#ifndef BZ_ACCUMULATE_PEEL
+#define BZ_ACCUMULATE_PEEL 1
+#endif
+  u32 first = lo;
+  if constexpr (BZ_ACCUMULATE_PEEL != 0) {
+    const typename C::operand q = C::stage(staged);
+    const bool negate = (e_cur >> 31) != 0;
+    const u32 next_entry = lo + 1 < hi ? e_next : e_cur;
+    e_cur = e_next;
+    staged = gather(next_entry);
+    if (lo + 2 < hi) e_next = idx[lo + 2];
+    if constexpr (C::has_signed_gather) {
+      acc = C::first_gathered(q, negate);
+    } else {
+      acc = C::first(q, negate);
+    }
+    first = lo + 1;
+    // (materialised here: left to itself hipcc no longer updates the loop's accumulator in place
+    // and copies it at the end of every iteration -- curve25519 36 v_mov_b32, 140 -> 179 VGPRs
+    // -- C::first_pinned; the Weierstrass loops are better off without)
+    if constexpr (C::first_pinned) {
+      u32* w = reinterpret_cast<u32*>(&acc);
+#pragma unroll
+      for (u32 k = 0; k < sizeof(acc) / 4; ++k) asm volatile("" : "+v"(w[k]));
+    }
+  }
+  for (u32 i = first; i < hi; ++i) {
     // the staged row first: the waits hipcc puts in front of its registers count every memory
     // operation of the wavefront in order, so behind the flush block they would also wait for the
     // block's nine stores to complete (curve25519 k_accumulate 0.629 -> 0.625 ms alone, 0.655 ->

@@ -268,6 +268,26 @@ def sw29_dbl_n(cid, a, k):
     return out
 
 
+def ed29_chain_first(points, negate, niels=False):
+    """a lane of k_accumulate: first entry loaded (one product), the others added"""
+    out = np.zeros(20, np.uint64)
+    pts = _c(points)
+    neg = _c(negate, np.int32)
+    lib().bz_ed29_chain_first(_p(out), _p(pts), _p(neg), ctypes.c_int(pts.shape[0]),
+                              ctypes.c_int(1 if niels else 0))
+    return out
+
+
+def sw29_chain_lifted(cid, affine_xy, negate):
+    """a lane of k_accumulate: first affine entry lifted (Z = 1), the others added (add_mixed_acc)"""
+    out = np.zeros(3 * LIMBS[cid], np.uint64)
+    xy = _c(affine_xy)
+    neg = _c(negate, np.int32)
+    getattr(lib(), f"bz_{PFX[cid]}_29_chain_lifted")(_p(out), _p(xy), _p(neg),
+                                                     ctypes.c_int(xy.shape[0]))
+    return out
+
+
 def sw29_chain(cid, start, affine_xy, negate):
     out = np.zeros(3 * LIMBS[cid], np.uint64)
     xy = _c(affine_xy)

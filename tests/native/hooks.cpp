@@ -387,6 +387,27 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
   std::memcpy(out, &e, 160);
 }
 
+// what a lane of k_accumulate does with its segment: the first entry loaded (from_cached_presigned /
+// from_niels), the others added
+void bz_ed29_chain_first(u64* out, const u64* points, const int* negate, int n, int niels) {
+  ed29_point acc = ed29::identity();
+  for (int i = 0; i < n; ++i) {
+    ed_point q;
+    std::memcpy(&q, points + 20 * i, 160);
+    const bool neg = negate[i] != 0;
+    if (niels != 0) {
+      const ed29_niels row = ed29::to_niels(ed29::from_ed(q));
+      acc = i == 0 ? ed29::from_niels(row, neg) : ed29::add_niels(acc, row, neg);
+    } else {
+      const ed29_cached_packed row[1] = {ed29::pack(ed29::cached_from_ed(q))};
+      const ed29_cached g = ed29::unpack(ed29::gather_signed(row, 0, neg));
+      acc = i == 0 ? ed29::from_cached_presigned(g, neg) : ed29::add_cached_presigned(acc, g, neg);
+    }
+  }
+  ed_point e = ed29::to_ed(acc);
+  std::memcpy(out, &e, 160);
+}
+
 // unsaturated-limb Montgomery fields / curves of the gfx950 kernels (field/mont29.h,
 // curve/sw29.h), driven through their ABI-form conversions; built with BZ_MONT29_CHECK so every
 // limb-level contract is asserted while the tests run
@@ -451,6 +472,22 @@ void bz_ed29_chain(u64* out, const u64* points, const int* negate, int n) {
     if (std::memcmp(&r, &rt, sizeof(r)) != 0) std::abort();                                        \
     std::memcpy(out, &r, sizeof(r));                                                               \
   }
+/* a lane of k_accumulate: the first affine entry lifted (lift_acc), the others added */
+#define BZ_SW29_LIFT_HOOK(PFX, G)                                                                  \
+  void bz_##PFX##_29_chain_lifted(u64* out, const u64* affine_xy, const int* negate, int n) {      \
+    constexpr int W = G::N64;                                                                      \
+    G::point acc = G::identity();                                                                  \
+    for (int i = 0; i < n; ++i) {                                                                  \
+      G::affine q = G::affine_from_mont64(affine_xy + 2 * W * i, affine_xy + 2 * W * i + W, false); \
+      acc = i == 0 ? G::lift_acc(q, negate[i] != 0)                                                \
+                   : G::template add_mixed_acc<true>(acc, q, negate[i] != 0);                      \
+    }                                                                                              \
+    G::G64::point r = G::to_point64(acc);                                                          \
+    std::memcpy(out, &r, sizeof(r));                                                               \
+  }
+BZ_SW29_LIFT_HOOK(bn254, bn254_g1_29)
+BZ_SW29_LIFT_HOOK(grumpkin, grumpkin_29)
+BZ_SW29_LIFT_HOOK(bls12_381, bls12_381_g1_28)
 BZ_SW29_HOOKS(bn254, bn254_g1_29)
 BZ_SW29_HOOKS(grumpkin, grumpkin_29)
 BZ_SW29_HOOKS(bls12_381, bls12_381_g1_28)

@@ -373,6 +373,18 @@ def test_ed29_group_law_matches_reference(oracle):
         acc = hooks.ed_sub(acc, q) if s else oracle.add_projective(0, acc, q)
     assert np.array_equal(canon(hooks.ed29_chain(g, signs)), canon(acc))
     assert np.array_equal(canon(hooks.ed29_chain(g, signs, niels=True)), canon(acc))
+    # k_accumulate loads the first entry of a segment instead of adding it to the identity
+    ident = oracle.one_commit(0)
+    for n in (1, 2, 40):
+        for first_sign in (0, 1):
+            sg = np.array(signs[:n])
+            sg[0] = first_sign
+            want = ident
+            for q, s in zip(g[:n], sg):
+                want = hooks.ed_sub(want, q) if s else oracle.add_projective(0, want, q)
+            for niels in (False, True):
+                assert np.array_equal(canon(hooks.ed29_chain_first(g[:n], sg, niels=niels)),
+                                      canon(want))
     # doubling and cancellation through the Z = 1 addends (unified formulas)
     twice = np.stack([g[0], g[0], g[1], g[1]])
     assert np.array_equal(canon(hooks.ed29_chain(twice, [0, 0, 0, 1], niels=True)),
@@ -480,12 +492,20 @@ def test_sw29_group_law_matches_reference(oracle, cid):
     # its invariant or differs from the general form in any coordinate
     long_order = rng.integers(0, len(order), 4000)
     hooks.sw29_chain(cid, ident, xy[long_order], rng.integers(0, 2, 4000))
+    # k_accumulate lifts the first entry of a segment (Z = 1) instead of adding it to the identity
+    for n in (1, 2, len(order)):
+        for first_sign in (0, 1):
+            sg = np.array(signs[:n])
+            sg[0] = first_sign
+            want = hooks.sw29_chain(cid, ident, xy[:n], sg)
+            assert np.array_equal(canon(hooks.sw29_chain_lifted(cid, xy[:n], sg)), canon(want))
+    hooks.sw29_chain_lifted(cid, xy[long_order], rng.integers(0, 2, 4000))
 
 
 @pytest.mark.parametrize("name,max_v,b3,negative,reduce_b3,k_minus,inv", [
     ("bn254", 169, 9, False, False, 16, (5, 4, 1.6)),
     ("bls12-381", 2520, 12, False, False, 16, (2, 2, 1.1)),
-    ("grumpkin", 169, 51, True, True, 8, (1.5, 1.5, 1.5)),
+    ("grumpkin", 169, 51, True, True, 8, (1.5, 2, 1.5)),
 ])
 def test_bucket_accumulator_invariant_is_a_fixed_point(name, max_v, b3, negative, reduce_b3,
                                                         k_minus, inv):
