@@ -165,6 +165,38 @@ BZ_HD ed29_point add_cached_presigned(const ed29_point& p, const ed29_cached& q,
   return r;
 }
 
+// add_cached_presigned in two halves: everything that reads p and q (four products), then the four
+// products of the result.  Between them neither operand is live (k_accumulate issues the next gather
+// there).
+struct ed29_completed {
+  fe29 ex, ey, ez, et;
+};
+BZ_HD ed29_completed add_cached_presigned_front(const ed29_point& p, const ed29_cached& q,
+                                                bool negate) {
+  const fe29 qt = f29::cneg_xad(q.T2d, negate);      // B 2
+  const fe29 ypx = f29::add(p.Y, p.X);               // B 2
+  const fe29 ymx = f29::sub(p.Y, p.X);               // B 3
+  const fe29 a = f29::mul(ypx, q.YpX);               // 2 * 1
+  const fe29 b = f29::mul(ymx, q.YmX);               // 3 * 1
+  const fe29 c = f29::mul(p.T, qt);                  // 1 * 2
+  const fe29 zz = f29::mul(p.Z, q.Z);                // 1 * 1
+  const fe29 d = f29::add(zz, zz);                   // B 2
+  ed29_completed m;
+  m.ez = f29::add(d, c);                             // B 3
+  m.et = f29::weak_reduce(f29::sub(d, c));           // B 4 -> 1
+  m.ex = f29::sub(a, b);                             // B 3
+  m.ey = f29::add(a, b);                             // B 2
+  return m;
+}
+BZ_HD ed29_point add_cached_back(const ed29_completed& m) {
+  ed29_point r;
+  r.X = f29::mul(m.ex, m.et); // 3 * 1
+  r.Y = f29::mul(m.ey, m.ez); // 2 * 3
+  r.Z = f29::mul(m.ez, m.et); // 3 * 1
+  r.T = f29::mul(m.ex, m.ey); // 3 * 2
+  return r;
+}
+
 // identity + q (q.YpX / q.YmX already exchanged when `negate`, as add_cached_presigned takes them)
 // without an addition: (2X : 2Y : 2Z : 2T) with 2T = (2dT) / d -- one field product instead of
 // eight.  k_accumulate's first entry of a segment: every lane of the wavefront holds the identity

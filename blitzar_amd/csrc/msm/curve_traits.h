@@ -81,6 +81,18 @@ struct ed25519_msm {
     acc = ed29::add_cached_presigned(acc, q, negate);
   }
   // identity + (+-q) of a segment's first entry: loaded, not added (k_accumulate)
+  // the addition in two halves with no operand live between them (k_accumulate, BZ_ACCUMULATE_DIRECT=2)
+  static constexpr bool has_split_add = true;
+  using completed = ed29::ed29_completed;
+  BZ_HD static completed add_front(const point& acc, const operand& q, bool negate) {
+    completed m = ed29::add_cached_presigned_front(acc, q, negate);
+    f29::pin(m.ex);
+    f29::pin(m.ey);
+    f29::pin(m.ez);
+    f29::pin(m.et);
+    return m;
+  }
+  BZ_HD static point add_back(const completed& m) { return ed29::add_cached_back(m); }
   static constexpr bool first_pinned = true; // (see k_accumulate)
   BZ_HD static point first_gathered(const operand& q, bool negate) {
     return ed29::from_cached_presigned(q, negate);
@@ -218,6 +230,7 @@ struct ed25519_niels_msm : ed25519_msm {
   BZ_HD static void accumulate(point& acc, const addend& q, bool negate) {
     acc = ed29::add_niels(acc, q, negate);
   }
+  static constexpr bool has_split_add = false;
   BZ_HD static point first(const addend& q, bool negate) { return ed29::from_niels(q, negate); }
   static constexpr bool has_signed_gather = false; // 36-byte limb pieces: no aligned exchange
   // an accumulated entry against Z = 1 addends relative to the per-call (Y+X, Y-X, Z, 2dT) form
@@ -430,6 +443,7 @@ template <class G29, unsigned CurveId> struct sw_msm_base {
   }
   // identity + (+-q) of a segment's first entry: the affine point itself (k_accumulate)
   static constexpr bool first_pinned = false;
+  static constexpr bool has_split_add = false;
   BZ_HD static point first(const operand& q, bool negate) {
     if (q.nonzero == 0) return G29::identity();
     return G29::lift_acc(q.a, negate);

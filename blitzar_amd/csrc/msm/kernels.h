@@ -1508,6 +1508,15 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
       return addends[entry & 0x7fffffffu];
     }
   };
+  // BZ_ACCUMULATE_DIRECT=1 (A/B): no row in flight across the addition -- 32 registers fewer, for a
+  // fourth wavefront per SIMD to hide the gather instead
+#ifndef BZ_ACCUMULATE_DIRECT
+#define BZ_ACCUMULATE_DIRECT 0
+#endif
+  // BZ_ACCUMULATE_DIRECT=2 (curves with C::has_split_add): the next row is requested between the two
+  // halves of the addition, where neither the accumulator nor the operand is live
+  constexpr bool kSplit = BZ_ACCUMULATE_DIRECT == 2 && C::has_split_add;
+  constexpr bool kDirect = BZ_ACCUMULATE_DIRECT == 1 || (BZ_ACCUMULATE_DIRECT == 2 && !kSplit);
   typename C::addend staged = gather(e_cur);
   // The first entry of a segment meets the identity in every lane of the wavefront (and never a
   // bucket boundary: `b` is the bucket that holds entry `lo`), so it is loaded, not added:
@@ -1522,7 +1531,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     const bool negate = (e_cur >> 31) != 0;
     const u32 next_entry = lo + 1 < hi ? e_next : e_cur;
     e_cur = e_next;
-    staged = gather(next_entry);
+    if constexpr (!kDirect) staged = gather(next_entry);
     if (lo + 2 < hi) e_next = idx[lo + 2];
     if constexpr (C::has_signed_gather) {
       acc = C::first_gathered(q, negate);
@@ -1544,6 +1553,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     // operation of the wavefront in order, so behind the flush block they would also wait for the
     // block's nine stores to complete (curve25519 k_accumulate 0.629 -> 0.625 ms alone, 0.655 ->
     // 0.648 in a sequence; the Weierstrass kernels unchanged)
+    if constexpr (kDirect) staged = gather(e_cur);
     const typename C::operand q = C::stage(staged);
     const bool negate = (e_cur >> 31) != 0;
     if (i == b_end) {
@@ -1564,12 +1574,21 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     // copies of the row and moves it back and forth (bn254: 16 v_mov_b64 per iteration)
     const u32 next_entry = i + 1 < hi ? e_next : e_cur;
     e_cur = e_next;
-    staged = gather(next_entry);
-    if (i + 2 < hi) e_next = idx[i + 2];
-    if constexpr (C::has_signed_gather) {
-      C::accumulate_gathered(acc, q, negate);
+    if constexpr (kSplit) {
+      const typename C::completed mid = C::add_front(acc, q, negate);
+      asm volatile("" ::: "memory");
+      staged = gather(next_entry);
+      if (i + 2 < hi) e_next = idx[i + 2];
+      asm volatile("" ::: "memory");
+      acc = C::add_back(mid);
     } else {
-      C::accumulate(acc, q, negate);
+      if constexpr (!kDirect) staged = gather(next_entry);
+      if (i + 2 < hi) e_next = idx[i + 2];
+      if constexpr (C::has_signed_gather) {
+        C::accumulate_gathered(acc, q, negate);
+      } else {
+        C::accumulate(acc, q, negate);
+      }
     }
   }
   // runs of `whole` lanes (necessarily of one bucket) -> one head per run and wavefront
