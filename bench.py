@@ -18,7 +18,8 @@ metric = scalar-point ops / s over the whole job, plus
   roofline      dominant kernel k_accumulate: algorithmic bytes per launch / its HIP-event duration
                 against 8 TB/s; `traffic` / `valu_busy` from the committed PMC passes; `alu_frac` =
                 the integer-ALU side (the binding bound) against the v_mad_u64_u32 issue rate
-                measured on THIS box in THIS run; `box_*`: which kind of box ran, its sustained step
+                measured on THIS box in THIS run, `issue_frac` = the same for the loop's whole
+                instruction mix (profiles/isa_counts.json); `box_*`: which kind of box ran, its sustained step
                 and lone call -- flat scalars only
   cpu_baseline  N = 1 only: the reference's own CPU backend (oracle/_ref) on THE SAME scalars; the
                 timed GPU commitment must equal its output or the bench aborts (`verified`)
@@ -287,6 +288,14 @@ def roofline_of(kernel, alg_bytes, accumulate_ms, additions=None, use_pmc=True):
                        "ps_per_addition": dur_s / additions * 1e12,
                        "peak_source": peak_source,
                        "source": "instruction counts: profiles/isa_counts.json (tools/prof/isa_count.py)"}
+        # the issue bound of the loop's OWN instruction mix (every VALU instruction at the measured
+        # issue cost of its class, relative to the probed multiply-add): what the kernel could reach
+        # with the arithmetic it has
+        if isa.get("issue_cycles_per_addition") and isa.get("mad_issue_cycles_per_addition"):
+            mix = isa["issue_cycles_per_addition"] / isa["mad_issue_cycles_per_addition"]
+            roof["alu"]["issue_frac"] = roof["alu"]["frac"] * mix
+            roof["alu"]["issue_cycles_per_wave_addition_isa"] = isa["issue_cycles_per_addition"]
+            roof["issue_frac"] = roof["alu"]["issue_frac"]
         # the driver's record keeps the scalars of `roofline`, not its nested objects
         roof["alu_frac"] = roof["alu"]["frac"]
         roof["alu_peak_wave_mads_per_s"] = peak
@@ -889,7 +898,7 @@ def box_record(roof, state, legs, lone_call_ms, lib):
 #--------------------------------------------------------------------------------------------------
 COMPACT_LIMIT = 4096
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                 "algorithmic_bytes_per_launch", "kernel_ms", "valu_busy", "alu_frac")
+                 "algorithmic_bytes_per_launch", "kernel_ms", "valu_busy", "alu_frac", "issue_frac")
 BOX_KEYS = ("box_fetch_kind", "box_asic_serial", "box_sustained_ms_per_step", "box_lone_call_ms",
             "box_sclk_mhz_under_sequence", "box_power_w_mean")
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",

@@ -84,3 +84,24 @@ def test_emit_prints_the_compact_record_last_and_writes_the_sidecar(bench, tmp_p
         detail = _strict(fh.read())
     assert detail["configs"] and detail["host_api"] and detail["value"] == full["value"]
     assert "detail_file" in d
+
+
+def test_issue_frac_prices_the_whole_instruction_mix(bench):
+    """`issue_frac` = `alu_frac` scaled by the loop's whole instruction mix over its multiply-adds
+    alone (profiles/isa_counts.json: every VALU instruction at the measured issue cost of its
+    class); it enters the compact record beside `alu_frac`."""
+    kernel = "k_accumulate<bz::ed25519_msm>"
+    with open(os.path.join(ROOT, "profiles", "isa_counts.json")) as fh:
+        isa = json.load(fh)["kernels"][kernel]
+    classes = isa["issue_classes"]
+    assert classes["mad64"] == isa["mads_per_addition"]
+    assert sum(classes.values()) == isa["loop_valu"]
+    assert isa["issue_cycles_per_addition"] > isa["mad_issue_cycles_per_addition"] > 0
+    roof = bench.roofline_of(kernel, 192 << 20, 0.64, additions=16 << 20)
+    mix = isa["issue_cycles_per_addition"] / isa["mad_issue_cycles_per_addition"]
+    assert roof["issue_frac"] == pytest.approx(roof["alu_frac"] * mix, rel=1e-9)
+    assert roof["alu_frac"] < roof["issue_frac"] < 1.05
+    full = _canned()
+    full["roofline"]["issue_frac"] = roof["issue_frac"]
+    d = _strict(bench.compact_record(full))
+    assert d["roofline"]["issue_frac"] == pytest.approx(roof["issue_frac"], rel=1e-5)

@@ -59,6 +59,25 @@ def classify(op):
     return "other"
 
 
+# Issue cost per wave-instruction and SIMD by class, in shader cycles at 8 waves per SIMD
+# (profiles/round2_valu_rates.txt, tools/ubench/valu_rates.hip): the 64-bit multiply-add, the other
+# instructions of the multiplier / 64-bit shifter class, plain 32-bit VALU.
+ISSUE_CYCLES = {"mad64": 4.47, "wide": 4.14, "plain": 2.37}
+WIDE_OPS = ("v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64", "v_lshl_add_u64", "v_add_co",
+            "v_addc_co", "v_add_u64", "v_alignbit_b32", "v_mul_lo_u32", "v_mul_hi_u32",
+            "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_mad_i32_i24", "v_mul_hi_i32")
+
+
+def issue_class(op):
+    if op.startswith("v_mad_u64_u32"):
+        return "mad64"
+    if op.startswith(WIDE_OPS):
+        return "wide"
+    if op.startswith("v_"):
+        return "plain"
+    return None
+
+
 def analyse(asm_path):
     text = open(asm_path).read().split("\n")
     out = {}
@@ -101,6 +120,7 @@ def analyse(asm_path):
                     best = (lo, k)
         counts = collections.Counter()
         whole = collections.Counter()
+        issue = collections.Counter()
         for k, line in enumerate(body):
             om = re.match(r"^\s+([a-z_0-9]+)", line)
             if not om or line.lstrip().startswith((";", ".")):
@@ -109,12 +129,21 @@ def analyse(asm_path):
             whole[c] += 1
             if best and best[0] <= k <= best[1]:
                 counts[c] += 1
+                ic = issue_class(om.group(1))
+                if ic:
+                    issue[ic] += 1
         valu = sum(v for c, v in counts.items() if c.startswith(("v_", "valu")))
         demangled = subprocess.run(["c++filt", name], capture_output=True,
                                    text=True).stdout.strip()
         short = re.sub(r"^void bz::(k_accumulate<bz::\w+>).*", r"\1", demangled)
         out[short] = {"loop_instructions": dict(sorted(counts.items())), "loop_valu": valu,
                       "mads_per_addition": counts.get("v_mad_u64_u32", 0),
+                      # issue bound of the loop's own instruction mix, cycles per wave-addition
+                      "issue_classes": dict(sorted(issue.items())),
+                      "issue_cycles_per_addition": round(
+                          sum(ISSUE_CYCLES[c] * v for c, v in issue.items()), 1),
+                      "mad_issue_cycles_per_addition": round(
+                          ISSUE_CYCLES["mad64"] * issue.get("mad64", 0), 1),
                       "loop_total": sum(counts.values()),
                       "kernel_total": sum(whole.values()), **meta.get(name, {})}
         i = j
