@@ -189,6 +189,11 @@ msm_context* msm_context_new() {
   flag("BLITZAR_AMD_CALL_TABLE_WAVE_CHAIN", ctx->wave_chain);
   flag("BLITZAR_AMD_NORMALISE_CALLER", ctx->normalise_caller);
   flag("BLITZAR_AMD_MERGED_WAITS", ctx->merged_waits);
+  if (const char* v = std::getenv("BLITZAR_AMD_ACC_LDS_PAD")) {
+    const unsigned long pad = std::strtoul(v, nullptr, 10);
+    BZ_RELEASE_ASSERT(pad <= 65536, "BLITZAR_AMD_ACC_LDS_PAD: at most 64 KiB of dynamic LDS");
+    ctx->acc_lds_pad = static_cast<u32>(pad);
+  }
   if (const char* v = std::getenv("BLITZAR_AMD_CALL_TABLE_BITS")) {
     const unsigned long b = std::strtoul(v, nullptr, 10);
     BZ_RELEASE_ASSERT(b == 0 || (b >= kCallTableMinBits && b <= kCallTableMaxBits),

@@ -274,6 +274,11 @@ struct msm_context {
   // 0.9729 ms with the single wait: k_reduce and the sort stretch by what the gaps gave up.  The step
   // in throughput mode is bound by the work of its stages, not by the packets between them.
   bool merged_waits = false;
+  // BLITZAR_AMD_ACC_LDS_PAD=<bytes>: dynamic LDS requested by k_accumulate (which uses none), i.e. a cap
+  // on its workgroups per compute unit -- 55000 leaves two of the three wavefronts per SIMD its
+  // registers allow, and the third slot's registers to whatever runs beside it (the tails of the
+  // previous calls in throughput mode)
+  u32 acc_lds_pad = 0;
   void join_two_back(hipStream_t stream, u64 k) {
     if (!merged_waits) {
       if (k >= 2 && (joined < k - 1 || stream != joined_on)) {
@@ -902,8 +907,8 @@ void msm_enqueue_batch(msm_context& ctx, u8* d_out, u32 out_stride, bool project
     ctx.table_pending = false;
   }
   ctx.timer.timed(timing, 3, as, [&] {
-    hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads), 0,
-                       as, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
+    hipLaunchKernelGGL((k_accumulate<C>), dim3(seg_blocks, num_tasks), dim3(kAccumulateThreads),
+                       ctx.acc_lds_pad, as, b.bucket_sums, b.heads, b.bucket_end, b.segment_bucket, b.sorted,
                        b.addends, b.tasks);
   });
   if (mode.piped) ctx.acc_done[k & 3].record(as);
