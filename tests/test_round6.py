@@ -102,3 +102,34 @@ def test_short_uniform_column_beside_a_long_running_kernel(oracle, tmp_path):
     col = np.load(cols_file)
     want = oracle.commit(0, [(col, False)], util.generators_for(0, 1 << 16))
     assert np.array_equal(np.array(got["out"], dtype=np.uint8), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve_id", [0, 1, 2, 3])
+@pytest.mark.parametrize("n", [200, 6000])
+def test_first_entry_of_a_segment_is_the_identity_generator(gpu_backend, oracle, curve_id, n):
+    """k_accumulate loads the first entry of a segment instead of adding it to the identity (C::first).
+    Here that entry is known: row 5 -- the identity among the Weierstrass generators of tests/util.py --
+    is the only row whose low scalar bits are 1, every other row's are 2 or 3, so it sorts to the front
+    of window 0 whatever the window width; the other columns put a negative digit (two's complement
+    -1) and a lone entry (every other scalar zero) there."""
+    api = gpu_backend
+    rng = np.random.default_rng(600 + 7 * curve_id + n)
+    gens = util.generators_for(curve_id, n)
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x0f
+    a[:, 0] = rng.integers(2, 4, n, dtype=np.uint8)
+    a[:, 1] = 0
+    a[5, 0] = 1
+    signed = rng.integers(0, 128, (n, 8), dtype=np.uint8)      # positive 64-bit values ...
+    signed[:, 0] = rng.integers(2, 4, n, dtype=np.uint8)
+    signed[:, 1] = 0
+    signed[5] = 0xff                                           # ... and -1 in row 5
+    lone = np.zeros((n, 32), dtype=np.uint8)
+    lone[5, 0] = 1
+    lone[n - 1, 3] = 7
+    cols = [(a, False), (signed, True), (lone, False)]
+    got = api.compute_pedersen_commitments(curve_id, cols, generators=util.api_generators(curve_id, gens))
+    want = oracle.commit(curve_id, cols, gens)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, f"columns {bad.tolist()} differ"
