@@ -1458,6 +1458,36 @@ template <class P> __device__ __forceinline__ P wave_shfl_down(const P& v, u32 d
 #else
 #define BZ_ACCUMULATE_WAVES(C) (C::accumulate_waves_per_simd)
 #endif
+// BZ_ACCUMULATE_NT (A/B): bit 0 -- the flushed sums / head partials leave through nontemporal stores
+// (written once here, read once by k_reduce: they need not displace the addend table from the caches);
+// bit 1 -- the sorted entries arrive through nontemporal loads (read once)
+#ifndef BZ_ACCUMULATE_NT
+#define BZ_ACCUMULATE_NT 0
+#endif
+template <class P> __device__ __forceinline__ void store_flushed(P* dst, const P& v) {
+  if constexpr ((BZ_ACCUMULATE_NT & 1) != 0) {
+    typedef u32 vec4 __attribute__((ext_vector_type(4)));
+    const u32* w = reinterpret_cast<const u32*>(&v);
+    u32* d = reinterpret_cast<u32*>(dst);
+    constexpr u32 words = sizeof(P) / 4;
+#pragma unroll
+    for (u32 k = 0; k + 4 <= words; k += 4) {
+      const vec4 piece = {w[k], w[k + 1], w[k + 2], w[k + 3]};
+      __builtin_nontemporal_store(piece, reinterpret_cast<vec4*>(d + k));
+    }
+#pragma unroll
+    for (u32 k = words & ~3u; k < words; ++k) __builtin_nontemporal_store(w[k], d + k);
+  } else {
+    *dst = v;
+  }
+}
+__device__ __forceinline__ u32 load_entry(const u32* p) {
+  if constexpr ((BZ_ACCUMULATE_NT & 2) != 0) {
+    return __builtin_nontemporal_load(p);
+  } else {
+    return *p;
+  }
+}
 template <class C>
 __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     k_accumulate(typename C::point* __restrict__ bucket_sums, typename C::point* __restrict__ heads,
@@ -1498,8 +1528,8 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
   const u32 last_bucket = task.num_buckets - 1;
   u32 next_end = ends[b < last_bucket ? b + 1 : last_bucket];
   typename C::point* flush_to = owned ? sums + b : heads + task.segment_base + seg;
-  u32 e_cur = idx[lo];
-  u32 e_next = lo + 1 < hi ? idx[lo + 1] : 0;
+  u32 e_cur = load_entry(idx + lo);
+  u32 e_next = lo + 1 < hi ? load_entry(idx + lo + 1) : 0;
   // (curves with C::has_signed_gather fetch the row in the order the digit's sign asks for)
   auto gather = [&](u32 entry) {
     if constexpr (C::has_signed_gather) {
@@ -1532,7 +1562,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     const u32 next_entry = lo + 1 < hi ? e_next : e_cur;
     e_cur = e_next;
     if constexpr (!kDirect) staged = gather(next_entry);
-    if (lo + 2 < hi) e_next = idx[lo + 2];
+    if (lo + 2 < hi) e_next = load_entry(idx + lo + 2);
     if constexpr (C::has_signed_gather) {
       acc = C::first_gathered(q, negate);
     } else {
@@ -1557,7 +1587,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     const typename C::operand q = C::stage(staged);
     const bool negate = (e_cur >> 31) != 0;
     if (i == b_end) {
-      *flush_to = acc;
+      store_flushed(flush_to, acc);
       ++b;
       b_end = next_end;
       while (b_end == i) { // empty buckets
@@ -1578,12 +1608,12 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
       const typename C::completed mid = C::add_front(acc, q, negate);
       asm volatile("" ::: "memory");
       staged = gather(next_entry);
-      if (i + 2 < hi) e_next = idx[i + 2];
+      if (i + 2 < hi) e_next = load_entry(idx + i + 2);
       asm volatile("" ::: "memory");
       acc = C::add_back(mid);
     } else {
       if constexpr (!kDirect) staged = gather(next_entry);
-      if (i + 2 < hi) e_next = idx[i + 2];
+      if (i + 2 < hi) e_next = load_entry(idx + i + 2);
       if constexpr (C::has_signed_gather) {
         C::accumulate_gathered(acc, q, negate);
       } else {
@@ -1603,7 +1633,7 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
     }
     if (whole && lane != 0 && ((whole_mask >> (lane - 1)) & 1) != 0) write_head = false;
   }
-  if (owned || write_head) *flush_to = acc;
+  if (owned || write_head) store_flushed(flush_to, acc);
 }
 
 // k_accumulate<C> is instantiated in a translation unit of its own per curve
