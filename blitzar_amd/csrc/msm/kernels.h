@@ -1531,11 +1531,16 @@ __global__ void __launch_bounds__(kAccumulateThreads, BZ_ACCUMULATE_WAVES(C))
   u32 e_cur = load_entry(idx + lo);
   u32 e_next = lo + 1 < hi ? load_entry(idx + lo + 1) : 0;
   // (curves with C::has_signed_gather fetch the row in the order the digit's sign asks for)
+  // BZ_ACCUMULATE_ROW_MASK (timing experiments only, WRONG results): every gather lands in the first
+  // mask + 1 rows of the table -- what the loop costs when its rows come from the nearest cache
+#ifndef BZ_ACCUMULATE_ROW_MASK
+#define BZ_ACCUMULATE_ROW_MASK 0x7fffffffu
+#endif
   auto gather = [&](u32 entry) {
     if constexpr (C::has_signed_gather) {
-      return C::gather(addends, entry & 0x7fffffffu, (entry >> 31) != 0);
+      return C::gather(addends, entry & BZ_ACCUMULATE_ROW_MASK, (entry >> 31) != 0);
     } else {
-      return addends[entry & 0x7fffffffu];
+      return addends[entry & BZ_ACCUMULATE_ROW_MASK];
     }
   };
   // BZ_ACCUMULATE_DIRECT=1 (A/B): no row in flight across the addition -- 32 registers fewer, for a
